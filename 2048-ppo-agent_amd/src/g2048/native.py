@@ -1,0 +1,235 @@
+"""ctypes binding of libg2048.so (C ABI: include/g2048.h).
+
+This is the only place the Python host side touches native code.  There is no CPU fallback: if the
+library is missing, or a tensor is not on a HIP device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+RNG_LEGACY = 0
+RNG_PARTITIONABLE = 1
+POLICY_DRUL = 0
+POLICY_RANDOM = 1
+MAX_FUSED_STEPS = 128
+
+_PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+LIB_PATH = os.environ.get("G2048_LIB", os.path.join(_PKG_ROOT, "lib", "libg2048.so"))
+
+_u32, _i32, _i64, _vp, _dbl = C.c_uint32, C.c_int, C.c_int64, C.c_void_p, C.c_double
+
+# name -> argtypes; every entry point declared in include/g2048.h
+SIGNATURES = {
+    "g2048_abi_version": [],
+    "g2048_split": [_u32, _u32, _vp, _i64, _i32, _vp],
+    "g2048_chain_keys": [_vp, _vp, _i64, _i32],
+    "g2048_init": [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "g2048_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "g2048_observe": [_vp, _vp, _i64, _vp],
+    "g2048_act_drul": [_vp, _vp, _i64, _vp],
+    "g2048_act_random": [_vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "g2048_act_logits": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp],
+    "g2048_reset_fused": [_u32, _u32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    "g2048_rollout_fused": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                            _i32, _i32, _i32, _vp, _vp],
+    "g2048_policy_step": [_u32, _u32, _u32, _u32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                          _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp],
+    "g2048_gae_tb": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _dbl, _dbl, _vp],
+    "g2048_gae_flat": [_vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp],
+    "g2048_compact": [_vp] * 14 + [_i64, _i64, _vp],
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libg2048.so or raise; never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"libg2048.so not found at {LIB_PATH}: build it with "
+                f"`python 2048-ppo-agent_amd/build.py` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the 2048 rollout engine."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        if lib.g2048_abi_version() != 1:
+            raise NativeError("libg2048.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        raise NativeError(f"{name} failed with code {rc}"
+                          + (" (invalid argument)" if rc == -1 else f" (hipError {-rc - 1000})"))
+
+
+def _dev(t: torch.Tensor | None, dtype, numel: int | None, name: str, optional=False):
+    if t is None:
+        if optional:
+            return None
+        raise NativeError(f"{name}: tensor required")
+    if not t.is_cuda:
+        raise NativeError(f"{name}: expected a HIP device tensor, got {t.device} (no CPU path exists)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise NativeError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    if numel is not None and t.numel() < numel:
+        raise NativeError(f"{name}: needs {numel} elements, has {t.numel()}")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+u8, i32, i64, f32 = torch.uint8, torch.int32, torch.int64, torch.float32
+# uint32 keys travel as int32 tensors (same bits); helpers below convert
+KEY_DTYPE = torch.int32
+
+
+def keys_from_numpy(a: np.ndarray, device) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a, np.uint32).view(np.int32)).to(device)
+
+
+def keys_to_numpy(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().numpy().view(np.uint32)
+
+
+# ------------------------------------------------------------------------------------------ host-only
+def chain_keys(key: np.ndarray, n: int, rng_mode: int):
+    """n x (key, sub = split(key)) on the host. Returns (new_key u32[2], subs u32[n,2])."""
+    k = np.array(key, dtype=np.uint32).reshape(2).copy()
+    subs = np.empty((n, 2), np.uint32)
+    _check(load().g2048_chain_keys(k.ctypes.data, subs.ctypes.data, n, rng_mode), "g2048_chain_keys")
+    return k, subs
+
+
+# ------------------------------------------------------------------------------------------ device calls
+def split(key, n: int, rng_mode: int, device) -> torch.Tensor:
+    out = torch.empty((n, 2), dtype=KEY_DTYPE, device=device)
+    _check(load().g2048_split(int(key[0]), int(key[1]), _dev(out, KEY_DTYPE, 2 * n, "out"), n, rng_mode,
+                              _stream()), "g2048_split")
+    return out
+
+
+def init(keys, boards, masks, done, rng_mode: int):
+    B = masks.numel()
+    _check(load().g2048_init(_dev(keys, KEY_DTYPE, 2 * B, "keys"), _dev(boards, u8, 16 * B, "boards"),
+                             _dev(masks, u8, B, "masks"), _dev(done, u8, B, "done"), B, rng_mode, _stream()),
+           "g2048_init")
+
+
+def step(boards, masks, done, actions, keys, rewards, rng_mode: int):
+    B = masks.numel()
+    _check(load().g2048_step(_dev(boards, u8, 16 * B, "boards"), _dev(masks, u8, B, "masks"),
+                             _dev(done, u8, B, "done"), _dev(actions, i32, B, "actions"),
+                             _dev(keys, KEY_DTYPE, 2 * B, "keys"), _dev(rewards, f32, B, "rewards"), B, rng_mode,
+                             _stream()), "g2048_step")
+
+
+def observe(boards, obs):
+    B = boards.numel() // 16
+    _check(load().g2048_observe(_dev(boards, u8, 16 * B, "boards"), _dev(obs, u8, 496 * B, "obs"), B, _stream()),
+           "g2048_observe")
+
+
+def act_drul(masks, actions):
+    B = masks.numel()
+    _check(load().g2048_act_drul(_dev(masks, u8, B, "masks"), _dev(actions, i32, B, "actions"), B, _stream()),
+           "g2048_act_drul")
+
+
+def act_random(keys, masks, actions, log_probs, rng_mode: int):
+    B = masks.numel()
+    _check(load().g2048_act_random(_dev(keys, KEY_DTYPE, 2 * B, "keys"), _dev(masks, u8, B, "masks"),
+                                   _dev(actions, i32, B, "actions"), _dev(log_probs, f32, B, "log_probs"), B,
+                                   rng_mode, _stream()), "g2048_act_random")
+
+
+def act_logits(keys, logits, masks, use_mask, sample, actions, log_probs, rng_mode: int):
+    B = masks.numel()
+    _check(load().g2048_act_logits(_dev(keys, KEY_DTYPE, 2 * B, "keys"), _dev(logits, f32, 4 * B, "logits"),
+                                   _dev(masks, u8, B, "masks"), int(bool(use_mask)), int(bool(sample)),
+                                   _dev(actions, i32, B, "actions"), _dev(log_probs, f32, B, "log_probs"), B,
+                                   rng_mode, _stream()), "g2048_act_logits")
+
+
+def reset_fused(sub, boards, masks, done, ep_len, B_total: int, env0: int, rng_mode: int):
+    B = masks.numel()
+    _check(load().g2048_reset_fused(int(sub[0]), int(sub[1]), _dev(boards, u8, 16 * B, "boards"),
+                                    _dev(masks, u8, B, "masks"), _dev(done, u8, B, "done"),
+                                    _dev(ep_len, i32, B, "ep_len"), B, B_total, env0, rng_mode, _stream()),
+           "g2048_reset_fused")
+
+
+def rollout_fused(step_subs: np.ndarray, t0: int, boards, masks, done, ep_len, tr_boards, tr_meta, tr_rewards,
+                  tr_logp, B_total: int, env0: int, policy: int, fill_frozen: bool, rng_mode: int, live_count):
+    B = masks.numel()
+    subs = np.ascontiguousarray(step_subs, np.uint32).reshape(-1, 4)
+    n = subs.shape[0]
+    need = (t0 + n) * B
+    _check(load().g2048_rollout_fused(subs.ctypes.data, n, t0, _dev(boards, u8, 16 * B, "boards"),
+                                      _dev(masks, u8, B, "masks"), _dev(done, u8, B, "done"),
+                                      _dev(ep_len, i32, B, "ep_len"), _dev(tr_boards, u8, 16 * need, "tr_boards"),
+                                      _dev(tr_meta, u8, need, "tr_meta"), _dev(tr_rewards, f32, need, "tr_rewards"),
+                                      _dev(tr_logp, f32, need, "tr_logp", optional=True), B, B_total, env0, policy,
+                                      int(bool(fill_frozen)), rng_mode, _dev(live_count, i32, 1, "live_count"),
+                                      _stream()), "g2048_rollout_fused")
+
+
+def policy_step(act_sub, step_sub, logits, values, use_mask, sample, t: int, boards, masks, done, ep_len, tr_boards,
+                tr_meta, tr_rewards, tr_logp, tr_values, B_total: int, env0: int, fill_frozen: bool, rng_mode: int,
+                live_count):
+    B = masks.numel()
+    need = (t + 1) * B
+    _check(load().g2048_policy_step(int(act_sub[0]), int(act_sub[1]), int(step_sub[0]), int(step_sub[1]),
+                                    _dev(logits, f32, 4 * B, "logits"), _dev(values, f32, B, "values"),
+                                    int(bool(use_mask)), int(bool(sample)), t, _dev(boards, u8, 16 * B, "boards"),
+                                    _dev(masks, u8, B, "masks"), _dev(done, u8, B, "done"),
+                                    _dev(ep_len, i32, B, "ep_len"), _dev(tr_boards, u8, 16 * need, "tr_boards"),
+                                    _dev(tr_meta, u8, need, "tr_meta"), _dev(tr_rewards, f32, need, "tr_rewards"),
+                                    _dev(tr_logp, f32, need, "tr_logp"), _dev(tr_values, f32, need, "tr_values"),
+                                    B, B_total, env0, int(bool(fill_frozen)), rng_mode,
+                                    _dev(live_count, i32, 1, "live_count"), _stream()), "g2048_policy_step")
+
+
+def gae_tb(tr_rewards, tr_values, ep_len, tr_adv, tr_ret, T: int, B: int, gamma: float, lam: float):
+    n = T * B
+    _check(load().g2048_gae_tb(_dev(tr_rewards, f32, n, "tr_rewards"), _dev(tr_values, f32, n, "tr_values"),
+                               _dev(ep_len, i32, B, "ep_len"), _dev(tr_adv, f32, n, "tr_adv"),
+                               _dev(tr_ret, f32, n, "tr_ret"), T, B, float(gamma), float(lam), _stream()),
+           "g2048_gae_tb")
+
+
+def gae_flat(rewards, values, terms, adv, ret, gamma: float, lam: float):
+    N = rewards.numel()
+    _check(load().g2048_gae_flat(_dev(rewards, f32, N, "rewards"), _dev(values, f32, N, "values"),
+                                 _dev(terms, u8, N, "terms"), _dev(adv, f32, N, "adv"), _dev(ret, f32, N, "ret"), N,
+                                 float(gamma), float(lam), _stream()), "g2048_gae_flat")
+
+
+def compact(tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, ep_len, offsets, out_boards, out_actions, out_masks,
+            out_rewards, out_logp, out_values, out_terms, T: int, B: int, N: int):
+    n = T * B
+    _check(load().g2048_compact(
+        _dev(tr_boards, u8, 16 * n, "tr_boards"), _dev(tr_meta, u8, n, "tr_meta"),
+        _dev(tr_rewards, f32, n, "tr_rewards"), _dev(tr_logp, f32, n, "tr_logp", optional=True),
+        _dev(tr_values, f32, n, "tr_values", optional=True), _dev(ep_len, i32, B, "ep_len"),
+        _dev(offsets, i64, B, "offsets"), _dev(out_boards, u8, 16 * N, "out_boards"),
+        _dev(out_actions, u8, N, "out_actions"), _dev(out_masks, u8, N, "out_masks"),
+        _dev(out_rewards, f32, N, "out_rewards"), _dev(out_logp, f32, N, "out_logp", optional=True),
+        _dev(out_values, f32, N, "out_values", optional=True), _dev(out_terms, u8, N, "out_terms"), T, B,
+        _stream()), "g2048_compact")

@@ -1,0 +1,137 @@
+/*
+ * g2048.h -- C ABI of libg2048.so, the MI355X (gfx950) 2048 rollout engine.
+ *
+ * This is the drop-in boundary of the hot path.  The reference (michaelriedl/2048-ppo-agent) is pure
+ * Python and has no FFI of its own: its hot path calls jitted JAX/Pgx functions.  Each entry point
+ * below names the reference call it replaces (paths relative to the reference repo); the ctypes
+ * binding a maintainer would add is shown in INTEGRATION.md and lives in
+ * 2048-ppo-agent_amd/src/g2048/native.py.
+ *
+ * Conventions
+ *   - All array pointers are DEVICE pointers owned by the caller (e.g. torch tensors); the library
+ *     never allocates, frees, copies to the host or synchronises.  Kernels are enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream).  Host-side arguments are marked (host).
+ *   - Return value: 0 on success, G2048_EINVAL (-1) for a bad argument, -(1000 + hipError_t) when the
+ *     launch itself failed.  Nothing throws.  Re-entrant: no global state.
+ *   - boards   u8[B][16]  log2(tile) per cell, row-major, 0 = empty, values <= 30; 16-byte aligned
+ *   - masks    u8[B]      bit a = legal_action_mask[a]  (0 left, 1 up, 2 right, 3 down)
+ *   - done     u8[B]      terminated flag (0/1)
+ *   - keys     u32[B][2]  one JAX threefry key per env
+ *   - rng_mode 0 = legacy threefry stream (jax_threefry_partitionable=False),
+ *              1 = partitionable stream (default of the reference's pinned jax 0.5.3)
+ *   - Trajectories are step-major SoA with row stride B:  x[t][e] at index t*B + e
+ *       tr_boards u8[T][B][16]  board BEFORE step t (the observation the policy saw)
+ *       tr_meta   u8[T][B]      action | mask_before << 2 | done_after << 6
+ *       tr_rewards/tr_logp/tr_values f32[T][B]
+ */
+#ifndef G2048_H
+#define G2048_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G2048_ABI_VERSION 1
+#define G2048_EINVAL (-1)
+#define G2048_RNG_LEGACY 0
+#define G2048_RNG_PARTITIONABLE 1
+#define G2048_POLICY_DRUL 0
+#define G2048_POLICY_RANDOM 1
+/* most lock-steps one g2048_rollout_fused launch can advance (its key table rides in the kernarg) */
+#define G2048_MAX_FUSED_STEPS 128
+
+int g2048_abi_version(void);
+
+/* ---- RNG ---------------------------------------------------------------------------------------- */
+
+/* out[j] = jax.random.split(key, n)[j].  Replaces `subkey = jax.random.split(subkey, batch_size)`
+ * (src/runs/batch_runner.py:106,119,127; src/runs/run_actions_batch.py:43,50,53). */
+int g2048_split(uint32_t key0, uint32_t key1, uint32_t *out_keys, int64_t n, int rng_mode, void *stream);
+
+/* (host, no device work) n times `key, sub = jax.random.split(key)`: key[2] is advanced in place,
+ * subs[i] = i-th sub-key.  Replaces the host-side chain at src/runs/batch_runner.py:105,118,126. */
+int g2048_chain_keys(uint32_t *key /*host [2]*/, uint32_t *subs /*host [n][2]*/, int64_t n, int rng_mode);
+
+/* ---- env, explicit per-env keys (the shape of the reference's vmapped calls) ----------------------- */
+
+/* jit(vmap(env.init))(keys)           src/runs/batch_runner.py:34,107 */
+int g2048_init(const uint32_t *keys, uint8_t *boards, uint8_t *masks, uint8_t *done, int64_t B,
+               int rng_mode, void *stream);
+
+/* jit(vmap(env.step))(state, action, keys), state updated in place.   src/runs/batch_runner.py:35,128
+ * Algorithmic traffic: 50 B per env (board 16 r + 16 w, action 4, key 8, reward 4, mask 1, done 1). */
+int g2048_step(uint8_t *boards, uint8_t *masks, uint8_t *done, const int32_t *actions,
+               const uint32_t *keys, float *rewards, int64_t B, int rng_mode, void *stream);
+
+/* State.observation: obs u8(bool)[B][4][4][31], obs[e][r][c][k] = (board == k).  Only for callers that
+ * want the reference's one-hot array (src/runs/batch_runner.py:121,138); the engine never needs it. */
+int g2048_observe(const uint8_t *boards, uint8_t *obs, int64_t B, void *stream);
+
+/* ---- act_fn plug-ins, batched ------------------------------------------------------------------- */
+
+/* src/actions/act_drul.py:40-44 */
+int g2048_act_drul(const uint8_t *masks, int32_t *actions, int64_t B, void *stream);
+/* src/actions/act_randomly.py:40-54 */
+int g2048_act_random(const uint32_t *keys, const uint8_t *masks, int32_t *actions, float *log_probs,
+                     int64_t B, int rng_mode, void *stream);
+/* tail of TorchActionFunction.__call__ (src/ppo/torch_action_wrapper.py:85-102) given the agent's raw
+ * actor logits f32[B][4]; use_mask applies src/ppo/ppo_agent.py:117-121 first. */
+int g2048_act_logits(const uint32_t *keys, const float *logits, const uint8_t *masks, int use_mask,
+                     int sample, int32_t *actions, float *log_probs, int64_t B, int rng_mode, void *stream);
+
+/* ---- fused rollout engine (keys derived in-kernel from the batch-wide sub-key) ---------------------
+ * env i of this call is global env (env0 + i) of a batch of B_total envs, so a shard reproduces exactly
+ * the slice of the single-device run (keys = split(sub, B_total)[env0 + i]). */
+
+/* init + zero ep_len.  sub = the sub-key of batch_runner.py:105-106. */
+int g2048_reset_fused(uint32_t sub0, uint32_t sub1, uint8_t *boards, uint8_t *masks, uint8_t *done,
+                      int32_t *ep_len, int64_t B, int64_t B_total, int64_t env0, int rng_mode, void *stream);
+
+/* n_steps lock-steps of BatchRunner's loop body (batch_runner.py:117-136) with a fused naive policy,
+ * boards resident in registers across steps.  step_subs (host) = [n_steps][4]: act sub-key, step sub-key.
+ * Writes steps t0..t0+n_steps-1 of the trajectory (tr_logp may be NULL; unused for DRUL).
+ * fill_frozen != 0 also writes the frozen frames of already-finished envs (what the reference's [B,T]
+ * arrays contain); 0 skips them and lets finished waves retire.  ep_len[e] counts steps through the first
+ * termination.  *live_count (device u32, zeroed by the caller) += envs still running afterwards. */
+int g2048_rollout_fused(const uint32_t *step_subs /*host*/, int n_steps, int64_t t0, uint8_t *boards,
+                        uint8_t *masks, uint8_t *done, int32_t *ep_len, uint8_t *tr_boards,
+                        uint8_t *tr_meta, float *tr_rewards, float *tr_logp, int64_t B, int64_t B_total,
+                        int64_t env0, int policy, int fill_frozen, int rng_mode, uint32_t *live_count,
+                        void *stream);
+
+/* One lock-step with the policy's outputs already on the device: sample (or argmax) from logits,
+ * log-prob, env step, trajectory write at step t -- the fusion of batch_runner.py:123-136 with
+ * torch_action_wrapper.py:85-102.  logits f32[B][4], values f32[B] come from the agent forward. */
+int g2048_policy_step(uint32_t act_sub0, uint32_t act_sub1, uint32_t step_sub0, uint32_t step_sub1,
+                      const float *logits, const float *values, int use_mask, int sample, int64_t t,
+                      uint8_t *boards, uint8_t *masks, uint8_t *done, int32_t *ep_len, uint8_t *tr_boards,
+                      uint8_t *tr_meta, float *tr_rewards, float *tr_logp, float *tr_values, int64_t B,
+                      int64_t B_total, int64_t env0, int fill_frozen, int rng_mode, uint32_t *live_count,
+                      void *stream);
+
+/* ---- rollout buffer + GAE ----------------------------------------------------------------------- */
+
+/* GAE over the step-major trajectory: env e uses steps 0..ep_len[e]-1 (its last kept step is terminal).
+ * Same float32 operation order as PPODataset._compute_gae_returns (src/ppo/data_loader.py:103-130),
+ * so results are bit-identical to the reference's scan over the compacted buffer. 17 B per env-step. */
+int g2048_gae_tb(const float *tr_rewards, const float *tr_values, const int32_t *ep_len, float *tr_adv,
+                 float *tr_ret, int64_t T, int64_t B, double gamma, double lam, void *stream);
+
+/* GAE over a flat buffer with termination flags (the reference's layout, data_loader.py:103-130). */
+int g2048_gae_flat(const float *rewards, const float *values, const uint8_t *terms, float *adv, float *ret,
+                   int64_t N, double gamma, double lam, void *stream);
+
+/* RolloutBuffer.store_batch (src/ppo/rollout_buffer.py:164-187): keep steps 0..ep_len[e]-1 of every env,
+ * env-major, at offsets[e] (exclusive prefix sum of ep_len, int64).  f32 outputs may be NULL with their
+ * inputs.  out_terms[n] = 1 on each env's last kept step. */
+int g2048_compact(const uint8_t *tr_boards, const uint8_t *tr_meta, const float *tr_rewards,
+                  const float *tr_logp, const float *tr_values, const int32_t *ep_len, const int64_t *offsets,
+                  uint8_t *out_boards, uint8_t *out_actions, uint8_t *out_masks, float *out_rewards,
+                  float *out_logp, float *out_values, uint8_t *out_terms, int64_t T, int64_t B, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G2048_H */

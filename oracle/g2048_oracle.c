@@ -284,7 +284,8 @@ void orc_act_logits(const uint32_t *keys, const float *logits, const uint8_t *ma
         double s = 0;
         for (int a = 0; a < 4; ++a) s += exp((double)l[a] - mx);
         actions[e] = act;
-        logp[e] = (float)((double)l[act] - (mx + log(s)));
+        volatile float lse = (float)(mx + log(s)); /* f32 logsumexp, as jax computes it */
+        logp[e] = l[act] - lse;
     }
 }
 

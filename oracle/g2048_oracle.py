@@ -281,7 +281,7 @@ def sample_policy(keys, logits, mode, sample=True):
     mx = logits.max(axis=1, keepdims=True)
     lse = (mx[:, 0].astype(np.float64)
            + np.log(np.exp((logits - mx).astype(np.float64)).sum(axis=1)))
-    logp = (logits[np.arange(len(action)), action].astype(np.float64) - lse).astype(np.float32)
+    logp = logits[np.arange(len(action)), action] - lse.astype(np.float32)  # f32, as jax
     return action, logp
 
 
