@@ -325,8 +325,60 @@ G_DEV u32 policy_drul(u32 mask) {
     return (mask & 8u) ? 3u : ((mask & 4u) ? 2u : ((mask & 2u) ? 1u : ((mask & 1u) ? 0u : 3u)));
 }
 
-// correctly rounded f32 log via f64 (so host oracle and device agree bit-for-bit)
-G_DEV float log_f32(float x) { return (float)log((double)x); }
+// Exactly-rounded single f32 multiply / add (never contracted into an FMA), so the host oracle and the
+// device evaluate the same sequence of IEEE operations.
+G_DEV float mul_rn(float a, float b) {
+#if G2048_ON_DEVICE
+    return __fmul_rn(a, b);
+#else
+    volatile float r = a * b;
+    return r;
+#endif
+}
+G_DEV float add_rn(float a, float b) {
+#if G2048_ON_DEVICE
+    return __fadd_rn(a, b);
+#else
+    volatile float r = a + b;
+    return r;
+#endif
+}
+
+// Natural log of a positive normal f32 in pure f32 arithmetic (Cephes logf polynomial, < 1 ulp typical).
+// jax computes the Gumbel noise with XLA's f32 log; any faithful f32 log reproduces the reference's
+// assets (tests/test_oracle_golden.py).  The oracle evaluates the identical operation sequence, so device
+// and oracle agree bit-for-bit; an f64 log here made the fused random-policy kernel latency-bound.
+G_DEV float log_f32(float x) {
+    u32 bits;
+#if G2048_ON_DEVICE
+    bits = __float_as_uint(x);
+#else
+    memcpy(&bits, &x, 4);
+#endif
+    int e = (int)((bits >> 23) & 0xFFu) - 126;
+    float m = u32_as_float((bits & 0x007FFFFFu) | 0x3F000000u);  // [0.5, 1)
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = add_rn(add_rn(m, m), -1.0f);
+    } else {
+        m = add_rn(m, -1.0f);
+    }
+    const float z = mul_rn(m, m);
+    float y = 7.0376836292E-2f;
+    y = add_rn(mul_rn(y, m), -1.1514610310E-1f);
+    y = add_rn(mul_rn(y, m), 1.1676998740E-1f);
+    y = add_rn(mul_rn(y, m), -1.2420140846E-1f);
+    y = add_rn(mul_rn(y, m), 1.4249322787E-1f);
+    y = add_rn(mul_rn(y, m), -1.6668057665E-1f);
+    y = add_rn(mul_rn(y, m), 2.0000714765E-1f);
+    y = add_rn(mul_rn(y, m), -2.4999993993E-1f);
+    y = add_rn(mul_rn(y, m), 3.3333331174E-1f);
+    y = mul_rn(mul_rn(y, m), z);
+    const float fe = (float)e;
+    y = add_rn(y, mul_rn(-2.12194440e-4f, fe));
+    y = add_rn(y, mul_rn(-0.5f, z));
+    return add_rn(add_rn(m, y), mul_rn(0.693359375f, fe));
+}
 
 G_DEV float gumbel(u32 bits) {
     const float tiny = 1.17549435e-38f;

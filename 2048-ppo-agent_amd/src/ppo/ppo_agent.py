@@ -1,0 +1,96 @@
+"""Actor-critic policy (state-dict compatible with the reference src/ppo/ppo_agent.py:11-191).
+
+Besides the reference's one-hot float observations [B, 16, 31] the agent accepts the engine's packed
+boards (uint8 [B, 16] of log2 tiles): the bias-free input Linear applied to a one-hot vector is a row
+gather from its weight, so the 496-element one-hot never has to exist.
+"""
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.distributions import Categorical
+
+from ..env_definitions import ACTION_DIM, OBS_DIM
+from .transformer_encoder import TransformerEncoder
+
+
+def _head(d_in: int, hidden: int, d_out: int) -> nn.Sequential:
+    return nn.Sequential(nn.Linear(d_in, hidden), nn.ReLU(), nn.Linear(hidden, hidden), nn.ReLU(),
+                         nn.Linear(hidden, d_out, bias=False))
+
+
+class _ActorCritic(nn.Module):
+    """Shared action/evaluation logic over ``features(observations) -> [B, d]``."""
+
+    def features(self, observations: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def forward(self, observations: torch.Tensor, action_mask: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (action_logits [B, action_dim], values [B, 1]); masked actions get ``logit - 1e8``."""
+        feats = self.features(observations)
+        logits = self.actor(feats)
+        if action_mask is not None:
+            logits = logits - 1e8 * (1 - action_mask.float())
+        return logits, self.critic(feats)
+
+    def get_action(self, observations, action_mask=None):
+        """Sample -> (actions, log_probs, values)."""
+        logits, values = self.forward(observations, action_mask)
+        dist = Categorical(logits=logits)
+        actions = dist.sample()
+        return actions, dist.log_prob(actions), values
+
+    def evaluate_actions(self, observations, actions, action_mask=None):
+        """-> (log_probs of ``actions``, values, entropy)."""
+        logits, values = self.forward(observations, action_mask)
+        dist = Categorical(logits=logits)
+        return dist.log_prob(actions), values, dist.entropy()
+
+
+class PPOAgent(_ActorCritic):
+    """Transformer encoder over the 16 cells (+CLS) with 3-layer actor and critic heads."""
+
+    def __init__(self, observation_dim: int = OBS_DIM, action_dim: int = ACTION_DIM, hidden_dim: int = 512,
+                 d_model: int = 256, nhead: int = 8, num_layers: int = 4, dim_feedforward: int = 1024,
+                 dropout: float = 0.1, reduction: str = "mean"):
+        super().__init__()
+        self.observation_dim, self.action_dim = observation_dim, action_dim
+        self.hidden_dim, self.reduction = hidden_dim, reduction
+        self.input_embedding = nn.Linear(observation_dim, d_model, bias=False)
+        self.transformer = TransformerEncoder(d_model=d_model, nhead=nhead, num_layers=num_layers,
+                                              dim_feedforward=dim_feedforward, dropout=dropout)
+        self.actor = _head(d_model, hidden_dim, action_dim)
+        self.critic = _head(d_model, hidden_dim, 1)
+
+    def embed(self, observations: torch.Tensor) -> torch.Tensor:
+        if observations.dtype in (torch.uint8, torch.int16, torch.int32, torch.int64):  # packed boards [B, 16]
+            return F.embedding(observations.long(), self.input_embedding.weight.t())
+        return self.input_embedding(observations)
+
+    def features(self, observations):
+        return self.transformer(self.embed(observations), reduction=self.reduction)
+
+
+class MLPAgent(_ActorCritic):
+    """MLP policy for BASELINE config 2 (the reference has none): the flattened one-hot board (16 x 31) through
+    a 2-layer ReLU trunk, then the same actor/critic heads and the same call interface as PPOAgent."""
+
+    def __init__(self, observation_dim: int = OBS_DIM, action_dim: int = ACTION_DIM, hidden_dim: int = 512,
+                 trunk_dim: int = 512, board_cells: int = 16):
+        super().__init__()
+        self.observation_dim, self.action_dim, self.hidden_dim = observation_dim, action_dim, hidden_dim
+        self.board_cells = board_cells
+        self.trunk_in = nn.Linear(board_cells * observation_dim, trunk_dim)
+        self.trunk_hidden = nn.Linear(trunk_dim, trunk_dim)
+        self.actor = _head(trunk_dim, hidden_dim, action_dim)
+        self.critic = _head(trunk_dim, hidden_dim, 1)
+
+    def features(self, observations):
+        if observations.dtype in (torch.uint8, torch.int16, torch.int32, torch.int64):
+            # one-hot @ W^T == sum over cells of the selected weight columns
+            cols = observations.long() + torch.arange(self.board_cells, device=observations.device) * self.observation_dim
+            h = F.embedding(cols, self.trunk_in.weight.t()).sum(dim=1) + self.trunk_in.bias
+        else:
+            h = self.trunk_in(observations.flatten(1))
+        return F.relu(self.trunk_hidden(F.relu(h)))

@@ -1,0 +1,384 @@
+"""PPO training loop (API of the reference src/ppo/ppo_trainer.py:21-727) on the device-resident pipeline.
+
+collect:  BatchRunner.collect -> engine Trajectory in HBM -> RolloutBuffer.store_trajectory (HIP compaction)
+update:   PPODataset (HIP GAE scan + z-scoring on the device) -> DeviceBatches -> clipped-surrogate/value/entropy
+          loss in PyTorch-ROCm (bf16 autocast, GradScaler, global-norm clip, AdamW/LAMB, per-minibatch LR step)
+Multi-GPU (torch.distributed initialised, backend nccl = RCCL): rollout_batch_size is the GLOBAL number of envs,
+each rank steps its contiguous slice with the global key indices (bit-identical to the single-device boards);
+per minibatch ONE all-reduce of the flat gradient bucket; advantage/return statistics and the KL early-stop
+test are reduced globally so every rank takes the same decisions.
+"""
+from __future__ import annotations
+
+import logging
+from collections import deque
+from typing import Dict, Literal, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch.amp import GradScaler, autocast
+
+from ..optim import configure_bert_optimizers
+from ..runs.batch_runner import BatchRunner
+from .data_loader import DeviceBatches, PPODataset
+from .rollout_buffer import RolloutBuffer
+from .torch_action_wrapper import TorchActionFunction
+
+logger = logging.getLogger(__name__)
+
+
+class _NullWriter:
+    """Stand-in when tensorboard is not installed: same calls, no output."""
+
+    def add_scalar(self, *a, **k):
+        pass
+
+    def add_histogram(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+
+def _make_writer(log_dir: str):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+
+        return SummaryWriter(log_dir)
+    except Exception:  # tensorboard missing
+        return _NullWriter()
+
+
+class _History(deque):
+    """deque that also answers slices (``hist[-100:]``): the reference slices its deque in
+    ppo_trainer.py:237-239,627,715 and run/train_ppo_agent.py:132, which raises TypeError there."""
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            return list(self)[idx]
+        return super().__getitem__(idx)
+
+
+def _tail(seq, k: int):
+    """Last k entries of a deque/list (the reference slices a deque here, which raises TypeError)."""
+    items = list(seq)
+    return items[-k:] if k > 0 else []
+
+
+class PPOTrainer:
+    def __init__(self, agent, batch_runner: BatchRunner, rollout_buffer: RolloutBuffer, optimizer_param_dict: Dict,
+                 max_steps: int, gamma: float = 0.99, lambda_gae: float = 0.95, clip_epsilon: float = 0.2,
+                 value_loss_coef: float = 0.5, entropy_coef: float = 0.01, max_grad_norm: float = 0.5,
+                 target_kl: float = 0.01, use_action_mask: bool = False, device: torch.device = torch.device("cpu"),
+                 mixed_precision: Optional[Literal["float16", "bfloat16"]] = "bfloat16",
+                 max_samples_per_epoch: int = None, shuffle_on_reset: bool = False, rollout_amp: bool = False,
+                 log_dir: str = "logs"):
+        self.agent = agent.to(device)
+        self.batch_runner = batch_runner
+        self.rollout_buffer = rollout_buffer
+        self.gamma, self.lambda_gae, self.clip_epsilon = gamma, lambda_gae, clip_epsilon
+        self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
+        self.max_grad_norm, self.target_kl = max_grad_norm, target_kl
+        self.use_action_mask = use_action_mask
+        self.device = torch.device(device)
+        self.max_samples_per_epoch, self.shuffle_on_reset = max_samples_per_epoch, shuffle_on_reset
+
+        self.mixed_precision = mixed_precision
+        self.use_amp = mixed_precision is not None and self.device.type == "cuda"
+        if self.use_amp:
+            self.scaler = GradScaler()
+            self.amp_dtype = torch.float16 if mixed_precision == "float16" else torch.bfloat16
+        else:
+            self.scaler, self.amp_dtype = None, None
+            if mixed_precision is not None:
+                logger.warning("Mixed precision requested but device is %s; disabled.", self.device.type)
+        # the reference rolls out in fp32; rollout_amp runs the rollout forward under the same autocast dtype
+        self.rollout_amp = rollout_amp and self.use_amp
+
+        opt = configure_bert_optimizers(self.agent, steps=max_steps, **dict(optimizer_param_dict))
+        self.optimizer = opt["optimizer"]
+        self.lr_scheduler = opt["lr_scheduler"]["scheduler"]
+
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self._group = dist.group.WORLD if self.world > 1 else None
+        self._flat_grad = None
+        if self.world > 1:
+            self._bind_flat_grads()
+            self._broadcast_parameters()
+
+        self.writer = _make_writer(log_dir) if self.rank == 0 else _NullWriter()
+        self.total_timesteps = 0
+        self.total_epochs = 0
+        self.total_update_steps = 0
+        hist = max_samples_per_epoch if max_samples_per_epoch is not None else 10000
+        self.episode_rewards = _History(maxlen=hist)
+        self.episode_lengths = _History(maxlen=hist)
+        self.last_save_timestep = 0
+        self.load_checkpoint_path = None
+        self.last_rollout_stats: Dict[str, float] = {}
+
+    # ------------------------------------------------------------------ multi-GPU plumbing
+    def _bind_flat_grads(self):
+        """One contiguous gradient bucket; every p.grad is a view into it -> a single all-reduce per step."""
+        params = [p for p in self.agent.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in params)
+        self._flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad = self._flat_grad[off:off + n].view_as(p)
+            off += n
+
+    def _broadcast_parameters(self):
+        for t in list(self.agent.parameters()) + list(self.agent.buffers()):
+            dist.broadcast(t.data, src=0, group=self._group)
+
+    def _zero_grad(self):
+        if self._flat_grad is not None:
+            self._flat_grad.zero_()
+        else:
+            self.optimizer.zero_grad()
+
+    def _allreduce_grads(self):
+        if self.world > 1:
+            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self._group)
+            self._flat_grad.div_(self.world)
+
+    def _shard(self, batch_size: int):
+        """This rank's slice of a global batch of ``batch_size`` envs."""
+        if self.world == 1:
+            return batch_size, 0, None
+        per = batch_size // self.world
+        if per * self.world != batch_size:
+            raise ValueError(f"rollout batch size {batch_size} must be divisible by world size {self.world}")
+        return per, self.rank * per, batch_size
+
+    # ------------------------------------------------------------------ collect
+    def collect_rollouts(self, batch_size: int, num_batches: int) -> None:
+        """``num_batches`` lock-step batches of ``batch_size`` complete episodes with the current policy."""
+        self.rollout_buffer.reset()
+        self.agent.eval()
+        act = TorchActionFunction(self.agent, use_mask=self.use_action_mask, device=self.device,
+                                  amp_dtype=self.amp_dtype if self.rollout_amp else None)
+        self.batch_runner.act_fn = act
+        local_b, env0, total = self._shard(batch_size)
+        self.batch_runner.env0, self.batch_runner.total_envs = env0, total
+        total_episodes = 0
+        ep_rew, ep_len = [], []
+        with torch.no_grad():
+            for _ in range(num_batches):
+                traj = self.batch_runner.collect(local_b)
+                self.rollout_buffer.store_trajectory(traj)
+                total_episodes += traj.B
+                # "episode reward" statistic of the reference: the largest single-step reward of the env's row
+                valid = traj.valid()
+                rmax = torch.where(valid, traj.rewards, torch.full_like(traj.rewards, float("-inf"))).max(dim=0).values
+                frozen_zero = traj.ep_len < traj.T  # rows padded with zero-reward frozen frames
+                rmax = torch.where(frozen_zero, rmax.clamp_min(0.0), rmax)
+                ep_rew.append(rmax)
+                ep_len.append(torch.where(traj.ep_len > 0, traj.ep_len, torch.full_like(traj.ep_len, traj.T)))
+        ep_rew = torch.cat(ep_rew).cpu().numpy()
+        ep_len = torch.cat(ep_len).cpu().numpy()
+        self.episode_rewards.extend(ep_rew.tolist())
+        self.episode_lengths.extend(ep_len.tolist())
+        n_local = self.rollout_buffer.buffer_size
+        if self.world > 1:
+            t = torch.tensor([n_local], dtype=torch.int64, device=self.device)
+            dist.all_reduce(t, group=self._group)
+            n_global = int(t.item())
+        else:
+            n_global = n_local
+        self.total_timesteps += n_global
+        logger.info("Collected %d timesteps from %d episodes", n_global, total_episodes * self.world)
+        if len(ep_rew):
+            self.last_rollout_stats = {
+                "mean_max_episode_reward": float(np.mean(ep_rew)), "max_episode_reward": float(np.max(ep_rew)),
+                "mean_episode_length": float(np.mean(ep_len)), "timesteps": n_global}
+            for k in ("mean_max_episode_reward", "max_episode_reward", "mean_episode_length"):
+                self.writer.add_scalar(f"rollout/{k}", self.last_rollout_stats[k], self.total_timesteps)
+
+    # ------------------------------------------------------------------ loss
+    def _compute_ppo_loss(self, observations, action_indices, action_masks, old_log_probs, advantages, returns):
+        """-> (total loss scalar, policy_loss [M], value_loss [M], entropy_loss [M], new_log_probs [M]).
+
+        ratio = exp(new - old); policy = -min(ratio*A, clip(ratio, 1-eps, 1+eps)*A); value = (V - R)^2 on the
+        z-scored returns; entropy = -H; total = mean(policy + c_v*value + c_e*entropy)."""
+        new_log_probs, values, entropy = self.agent.evaluate_actions(
+            observations, action_indices, action_mask=action_masks if self.use_action_mask else None)
+        ratio = torch.exp(new_log_probs - old_log_probs)
+        surr1 = ratio * advantages
+        surr2 = torch.clamp(ratio, 1 - self.clip_epsilon, 1 + self.clip_epsilon) * advantages
+        policy_loss = -torch.min(surr1, surr2)
+        value_loss = F.mse_loss(values.flatten(), returns, reduction="none")
+        entropy_loss = -entropy
+        loss = (policy_loss + self.value_loss_coef * value_loss + self.entropy_coef * entropy_loss).mean()
+        return loss, policy_loss, value_loss, entropy_loss, new_log_probs
+
+    def _unpack_batch(self, batch):
+        obs = batch["observations"]
+        actions = batch["actions"]
+        masks = batch["action_masks"]
+        if actions.dim() > 1:  # reference layout: one-hot float actions
+            actions = actions.argmax(dim=-1)
+        actions = actions.long()
+        if masks.dtype == torch.uint8 and masks.dim() == 1:  # packed bitmask -> [M, 4]
+            masks = (masks.unsqueeze(-1) & torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=masks.device)) != 0
+        return obs, actions, masks, batch["log_probs"], batch["advantages"], batch["returns"]
+
+    # ------------------------------------------------------------------ update
+    def update_policy(self, batch_size: int = 64, n_epochs: int = 4) -> Dict[str, float]:
+        """``n_epochs`` passes of minibatch PPO over the rollout buffer; early stop when mean(old - new log-prob)
+        of an epoch exceeds ``target_kl``."""
+        if self.rollout_buffer.buffer_size == 0:
+            logger.warning("No data in rollout buffer")
+            return {}
+        data = self.rollout_buffer.device_data(self.device)
+        dataset = PPODataset(data, gamma=self.gamma, lambda_gae=self.lambda_gae,
+                             max_samples_per_epoch=self.max_samples_per_epoch,
+                             shuffle_on_reset=self.shuffle_on_reset, group=self._group)
+        batches = DeviceBatches(dataset, batch_size, drop_last=True)
+        n_per_epoch = len(batches)
+        if self.world > 1:  # every rank must run the same number of collectives
+            t = torch.tensor([n_per_epoch], dtype=torch.int64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self._group)
+            n_per_epoch = int(t.item())
+        self.agent.train()
+        sums = torch.zeros(4, dtype=torch.float64, device=self.device)  # policy, value, entropy, total
+        n_updates = 0
+        mean_kl = 0.0
+        for epoch in range(n_epochs):
+            kl_sum = torch.zeros(1, dtype=torch.float64, device=self.device)
+            done_batches = 0
+            for batch in batches.epoch():
+                if done_batches >= n_per_epoch:
+                    break
+                obs, actions, masks, old_lp, adv, ret = self._unpack_batch(batch)
+                if self.use_amp:
+                    with autocast(device_type="cuda", dtype=self.amp_dtype):
+                        loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
+                else:
+                    loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
+                self._zero_grad()
+                if self.use_amp:
+                    self.scaler.scale(loss).backward()
+                    self._allreduce_grads()
+                    self.scaler.unscale_(self.optimizer)
+                    torch.nn.utils.clip_grad_norm_(self.agent.parameters(), self.max_grad_norm)
+                    self.scaler.step(self.optimizer)
+                    self.scaler.update()
+                else:
+                    loss.backward()
+                    self._allreduce_grads()
+                    torch.nn.utils.clip_grad_norm_(self.agent.parameters(), self.max_grad_norm)
+                    self.optimizer.step()
+                self.lr_scheduler.step()
+                with torch.no_grad():
+                    sums += torch.stack([pl.mean(), vl.mean(), el.mean(), loss.detach()]).double()
+                    kl_sum += (old_lp - new_lp).mean().double()
+                n_updates += 1
+                done_batches += 1
+                self.total_update_steps += 1
+            self.total_epochs += 1
+            if self.world > 1:
+                dist.all_reduce(kl_sum, group=self._group)
+                kl_sum /= self.world
+            mean_kl = float(kl_sum.item()) / done_batches if done_batches else 0.0
+            if mean_kl > self.target_kl:
+                logger.info("Early stopping at epoch %d due to high KL divergence: %.6f", epoch, mean_kl)
+                break
+        s = (sums / max(n_updates, 1)).tolist()
+        metrics = {"policy_loss": s[0] if n_updates else 0, "value_loss": s[1] if n_updates else 0,
+                   "entropy_loss": s[2] if n_updates else 0, "total_loss": s[3] if n_updates else 0,
+                   "kl_divergence": mean_kl, "n_updates": n_updates}
+        for k, v in metrics.items():
+            self.writer.add_scalar(f"train/{k}", v, self.total_timesteps)
+        if self.lr_scheduler is not None:
+            self.writer.add_scalar("train/lr", self.lr_scheduler.get_last_lr()[0], self.total_timesteps)
+        self.writer.add_scalar("train/total_epochs", self.total_epochs, self.total_timesteps)
+        self.writer.add_scalar("train/total_update_steps", self.total_update_steps, self.total_timesteps)
+        if not isinstance(self.writer, _NullWriter):
+            for name, p in self.agent.named_parameters():
+                self.writer.add_histogram(f"train/param_magnitude/{name}", p.data, self.total_timesteps)
+        return metrics
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, filename: str) -> None:
+        """torch.save of the reference's checkpoint dict (same keys; rank 0 only in a multi-GPU run)."""
+        if self.rank != 0:
+            return
+        ckpt = {
+            "agent_state_dict": self.agent.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+            "total_timesteps": self.total_timesteps, "total_epochs": self.total_epochs,
+            "total_update_steps": self.total_update_steps, "episode_rewards": list(self.episode_rewards),
+            "episode_lengths": list(self.episode_lengths), "last_save_timestep": self.last_save_timestep,
+        }
+        if self.use_amp and self.scaler is not None:
+            ckpt["scaler_state_dict"] = self.scaler.state_dict()
+        torch.save(ckpt, filename)
+        logger.info("Checkpoint saved to %s (timesteps: %d)", filename, self.total_timesteps)
+
+    def load_checkpoint(self, filename: str, load_optimizer: bool = False) -> None:
+        """Restore agent weights and counters; optimizer/scaler state only when asked / available."""
+        self.load_checkpoint_path = filename
+        ckpt = torch.load(filename, map_location=self.device, weights_only=False)
+        missing = [k for k in ("agent_state_dict", "optimizer_state_dict") if k not in ckpt]
+        if missing:
+            raise ValueError(f"Checkpoint missing required keys: {missing}")
+        self.agent.load_state_dict(ckpt["agent_state_dict"])
+        if load_optimizer:
+            try:
+                self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+            except Exception as e:  # keep training with a fresh optimizer, as the reference does
+                logger.warning("Failed to load optimizer state: %s", e)
+        self.total_timesteps = ckpt.get("total_timesteps", 0)
+        self.total_epochs = ckpt.get("total_epochs", 0)
+        self.total_update_steps = ckpt.get("total_update_steps", 0)
+        hist = self.episode_rewards.maxlen
+        self.episode_rewards = _History(ckpt.get("episode_rewards", []), maxlen=hist)
+        self.episode_lengths = _History(ckpt.get("episode_lengths", []), maxlen=hist)
+        self.last_save_timestep = ckpt.get("last_save_timestep", 0)
+        if self.use_amp and self.scaler is not None and "scaler_state_dict" in ckpt:
+            try:
+                self.scaler.load_state_dict(ckpt["scaler_state_dict"])
+            except Exception as e:
+                logger.warning("Failed to load GradScaler state: %s", e)
+        if self._flat_grad is not None:
+            self._bind_flat_grads()
+        logger.info("Checkpoint loaded: %d timesteps, %d epochs, %d update steps", self.total_timesteps,
+                    self.total_epochs, self.total_update_steps)
+        if self.episode_rewards:
+            logger.info("  - Recent mean reward: %.2f", float(np.mean(_tail(self.episode_rewards, 100))))
+
+    # ------------------------------------------------------------------ main loop
+    def train(self, total_timesteps: int, rollout_batch_size: int = 32, rollout_batches: int = 4,
+              update_epochs: int = 4, train_batch_size: int = 64, save_freq: int = 10000,
+              resume_extend_steps: bool = True) -> None:
+        """collect -> update until ``total_timesteps`` more (``resume_extend_steps``) or in total have been
+        gathered; ``checkpoint_{iteration}.pt`` every ``save_freq`` timesteps and ``final_model.pt`` at the end."""
+        start = self.total_timesteps
+        target = start + total_timesteps if resume_extend_steps else total_timesteps
+        verb = "Resuming" if self.load_checkpoint_path is not None else "Starting"
+        logger.info("%s training from %d timesteps to reach %d", verb, start, target)
+        if start >= target:
+            logger.warning("Already trained for %d timesteps, target is %d. No training needed.", start, target)
+            return
+        iteration = 0
+        while self.total_timesteps < target:
+            iteration += 1
+            self.collect_rollouts(rollout_batch_size, rollout_batches)
+            metrics = self.update_policy(batch_size=train_batch_size, n_epochs=update_epochs)
+            logger.info("Iteration %d, Timesteps: %d/%d", iteration, self.total_timesteps, target)
+            if metrics:
+                logger.info("Policy Loss: %.4f, Value Loss: %.4f, Entropy: %.4f", metrics["policy_loss"],
+                            metrics["value_loss"], metrics["entropy_loss"])
+            if self.episode_rewards:
+                logger.info("Mean Episode Reward (last 100): %.2f", float(np.mean(_tail(self.episode_rewards, 100))))
+            if self.total_timesteps - self.last_save_timestep >= save_freq:
+                self.save_checkpoint(f"checkpoint_{iteration}.pt")
+                self.last_save_timestep = self.total_timesteps
+        logger.info("Training completed!")
+        self.save_checkpoint("final_model.pt")
+        self.writer.close()

@@ -1,0 +1,78 @@
+"""Policy -> act_fn bridge (API of the reference src/ppo/torch_action_wrapper.py:10-104).
+
+The reference converts the torch agent to JAX (torch2jax) so it can be vmapped next to the Pgx env.  Here the
+env lives on the GPU, so the agent simply runs batched in PyTorch-ROCm on the packed boards and the tail of
+``__call__`` (clamp, categorical draw from the JAX-compatible key stream, log-softmax pick) is fused with the
+env step in ``g2048_policy_step`` / available stand-alone as ``g2048_act_logits``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ..actions import _common as C
+from ..env_definitions import BOARD_FLAT_DIM, OBS_DIM
+from ..g2048 import native as nv
+
+
+class TorchActionFunction:
+    """Wrap an actor-critic ``agent`` as an ``act_fn`` plug-in for BatchRunner.
+
+    Parameters mirror the reference: ``agent``, ``use_mask`` (apply the legal-action mask to the logits),
+    ``sample_actions`` (categorical sample vs argmax), ``device`` (where the agent runs).  Extra:
+    ``amp_dtype`` runs the rollout forward under autocast (the reference rolls out in fp32), ``sync_every``
+    is how many lock-steps are enqueued between polls of the device-side live-env counter.
+    Side effect as in the reference: ``agent`` is moved to ``device`` and put in eval mode.
+    """
+
+    def __init__(self, agent, use_mask: bool = False, sample_actions: bool = True,
+                 device: torch.device = torch.device("cpu"), amp_dtype: Optional[torch.dtype] = None,
+                 sync_every: int = 8, rng_mode=None):
+        self.agent = agent.to(device).eval()
+        self.use_mask = use_mask
+        self.sample_actions = sample_actions
+        self.device = device
+        self.amp_dtype = amp_dtype
+        self.sync_every = sync_every
+        self.rng_mode = rng_mode
+        self._agent_params = dict(self.agent.named_parameters())
+        self._agent_buffers = dict(self.agent.named_buffers())
+        self._agent_state = {**self._agent_params, **self._agent_buffers}
+
+    # batched device path used by the rollout engine: raw actor logits (masking happens in the kernel)
+    @torch.no_grad()
+    def policy_fn(self, boards: torch.Tensor, masks: torch.Tensor):
+        """boards u8 [B, 16], masks u8 [B] (unused here) -> (logits f32 [B, 4], values f32 [B])."""
+        agent_dev = next(self.agent.parameters()).device
+        x = boards if boards.device == agent_dev else boards.to(agent_dev)
+        if self.amp_dtype is not None and agent_dev.type == "cuda":
+            with torch.autocast(device_type="cuda", dtype=self.amp_dtype):
+                logits, values = self.agent(x, None)
+        else:
+            logits, values = self.agent(x, None)
+        return logits.float().to(boards.device), values.float().reshape(-1).to(boards.device)
+
+    @torch.no_grad()
+    def __call__(self, rng_key, obs, mask):
+        """Un-batched plug-in protocol: ``(rng_key[2], obs[4,4,31], mask[4]) -> (action, log_prob, value)``.
+        Leading batch dimensions are accepted.  The draw and the log-prob come from ``g2048_act_logits``."""
+        obs_t = torch.as_tensor(np.asarray(obs.cpu() if isinstance(obs, torch.Tensor) else obs))
+        batched = obs_t.ndim > 3
+        obs_t = obs_t.reshape(-1, BOARD_FLAT_DIM, OBS_DIM).float()
+        agent_dev = next(self.agent.parameters()).device
+        logits, values = self.agent(obs_t.to(agent_dev), None)
+        dev = C.device()
+        bits = C.mask_to_bits(mask)
+        keys = C.keys_tensor(rng_key)
+        n = bits.numel()
+        actions = torch.empty(n, dtype=torch.int32, device=dev)
+        logp = torch.empty(n, dtype=torch.float32, device=dev)
+        mode = C.default_rng_mode() if self.rng_mode is None else self.rng_mode
+        nv.act_logits(keys, logits.float().to(dev).contiguous(), bits, self.use_mask, self.sample_actions, actions,
+                      logp, mode)
+        a, lp, v = actions.cpu().numpy(), logp.cpu().numpy(), values.float().reshape(-1).cpu().numpy()
+        if batched:
+            return a, lp, v
+        return np.int32(a[0]), np.float32(lp[0]), np.float32(v[0])

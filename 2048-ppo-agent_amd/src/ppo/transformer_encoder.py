@@ -1,0 +1,98 @@
+"""Transformer trunk of the policy (state-dict compatible with the reference src/ppo/transformer_encoder.py).
+
+Parameter/buffer names are the reference's (``positional_encoding.{inv_freq,pe}``, ``cls_token``,
+``encoder.layers.N.*`` of ``nn.TransformerEncoder``) so checkpoints interchange; the forward is written
+out explicitly (pre-norm layers over fused QKV + SDPA) so the rollout and update paths control dtype and
+can be captured in hipGraphs.  The GEMMs run on MFMA through hipBLASLt.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..env_definitions import BOARD_DIM
+
+
+def get_emb(sin_inp: torch.Tensor) -> torch.Tensor:
+    """Interleave sin and cos of ``sin_inp`` along the last axis: [..., n] -> [..., 2n]."""
+    return torch.stack((sin_inp.sin(), sin_inp.cos()), dim=-1).flatten(-2, -1)
+
+
+class PositionalEncoding2D(nn.Module):
+    """Fixed 2-D sinusoidal code: the first half of the channels encodes the row, the second the column.
+
+    Buffers: ``inv_freq`` [channels/2] and ``pe`` [1, x, y, 2*channels] with channels = 2*ceil(C/4).
+    """
+
+    def __init__(self, x_size, y_size, channels, dropout=0.1, dtype_override=None):
+        super().__init__()
+        self.org_channels = channels
+        self.dtype_override = dtype_override
+        self.channels = int(math.ceil(channels / 4) * 2)
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, self.channels, 2).float() / self.channels))
+        self.register_buffer("inv_freq", inv_freq)
+        self.dropout = nn.Dropout(p=dropout)
+        ex = get_emb(torch.outer(torch.arange(x_size, dtype=inv_freq.dtype), inv_freq))  # [x, channels]
+        ey = get_emb(torch.outer(torch.arange(y_size, dtype=inv_freq.dtype), inv_freq))  # [y, channels]
+        pe = torch.zeros((x_size, y_size, 2 * self.channels), dtype=torch.float)
+        pe[:, :, : self.channels] = ex[:, None, :]
+        pe[:, :, self.channels:] = ey[None, :, :]
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def flat_table(self) -> torch.Tensor:
+        """[x*y, C] table in row-major cell order."""
+        return self.pe.reshape(-1, self.org_channels)
+
+    def forward(self, tensor):  # [B, x, y, C]
+        return self.dropout(tensor + self.pe[:, : tensor.shape[1], : tensor.shape[2]])
+
+    def forward_flat(self, tensor: torch.Tensor) -> torch.Tensor:  # [B, x*y, C]
+        return self.dropout(tensor + self.flat_table().unsqueeze(0))
+
+    def forward_with_inds(self, x: torch.Tensor, inds: torch.Tensor) -> torch.Tensor:  # [B, S, C], [B, S]
+        return self.dropout(x + self.flat_table()[inds])
+
+
+class TransformerEncoder(nn.Module):
+    """CLS token + 16 board tokens through ``num_layers`` pre-norm encoder layers; reduce to [B, d_model]."""
+
+    def __init__(self, d_model: int, nhead: int, num_layers: int, dim_feedforward: int, dropout: float = 0.1):
+        super().__init__()
+        self.d_model, self.nhead, self.num_layers = d_model, nhead, num_layers
+        self.dim_feedforward, self.dropout = dim_feedforward, dropout
+        self.positional_encoding = PositionalEncoding2D(BOARD_DIM[0], BOARD_DIM[1], channels=d_model, dropout=dropout)
+        self.cls_token = nn.Parameter(torch.randn(1, 1, d_model))
+        # parameter container with the reference's names; its own forward is not used
+        self.encoder = nn.TransformerEncoder(
+            nn.TransformerEncoderLayer(d_model=d_model, nhead=nhead, dim_feedforward=dim_feedforward, dropout=dropout,
+                                       norm_first=True, batch_first=True),
+            num_layers=num_layers, enable_nested_tensor=False)
+
+    def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor) -> torch.Tensor:
+        B, S, D = x.shape
+        H = self.nhead
+        p = self.dropout if self.training else 0.0
+        attn = layer.self_attn
+        h = F.layer_norm(x, (D,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+        qkv = F.linear(h, attn.in_proj_weight, attn.in_proj_bias).view(B, S, 3, H, D // H)
+        q, k, v = qkv.unbind(dim=2)
+        a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), dropout_p=p)
+        a = F.linear(a.transpose(1, 2).reshape(B, S, D), attn.out_proj.weight, attn.out_proj.bias)
+        x = x + F.dropout(a, p, self.training)
+        h = F.layer_norm(x, (D,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+        f = F.dropout(F.relu(F.linear(h, layer.linear1.weight, layer.linear1.bias)), p, self.training)
+        f = F.linear(f, layer.linear2.weight, layer.linear2.bias)
+        return x + F.dropout(f, p, self.training)
+
+    def forward(self, src: torch.Tensor, reduction: str = "mean") -> torch.Tensor:
+        """``src`` [B, 16, d_model] token embeddings (no positions yet) -> [B, d_model]."""
+        if reduction not in ["mean", "cls"]:
+            raise ValueError(f"reduction must be 'mean' or 'cls', got {reduction}")
+        x = self.positional_encoding.forward_flat(src)
+        x = torch.cat([self.cls_token.to(x.dtype).expand(x.shape[0], -1, -1), x], dim=1)
+        for layer in self.encoder.layers:
+            x = self._layer(layer, x)
+        if self.encoder.norm is not None:
+            x = self.encoder.norm(x)
+        return x[:, 0, :] if reduction == "cls" else x[:, 1:, :].mean(dim=1)

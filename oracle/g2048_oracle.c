@@ -109,13 +109,47 @@ static float uniform_f32(uint32_t bits) {
     return f - 1.0f;
 }
 
+/* correctly rounded f32 log (via f64): used where the reference takes log of 1/n (act_randomly) */
 static float log_f32(float x) { return (float)log((double)x); }
+
+/* f32 log evaluated entirely in IEEE f32 mul/add (Cephes logf polynomial).  jax draws its Gumbel noise
+ * with XLA's f32 log; this is the faithful f32 log all three implementations (this file, the numpy
+ * oracle, the HIP kernels) evaluate operation-for-operation, so they agree bit-for-bit.  The compile
+ * flags (-ffp-contract=off) and the volatile temporaries keep every operation individually rounded. */
+static float log_f32_poly(float x) {
+    static const float P[9] = {7.0376836292E-2f, -1.1514610310E-1f, 1.1676998740E-1f, -1.2420140846E-1f,
+                               1.4249322787E-1f, -1.6668057665E-1f, 2.0000714765E-1f, -2.4999993993E-1f,
+                               3.3333331174E-1f};
+    uint32_t bits;
+    memcpy(&bits, &x, 4);
+    int e = (int)((bits >> 23) & 0xFFu) - 126;
+    uint32_t mb = (bits & 0x007FFFFFu) | 0x3F000000u;
+    volatile float m, z, y, t;
+    float mf;
+    memcpy(&mf, &mb, 4);
+    m = mf;
+    if (m < 0.707106781186547524f) { e -= 1; t = m + m; m = t + -1.0f; }
+    else { m = m + -1.0f; }
+    z = m * m;
+    y = P[0];
+    for (int i = 1; i < 9; ++i) { t = y * m; y = t + P[i]; }
+    t = y * m;
+    y = t * z;
+    const float fe = (float)e;
+    t = -2.12194440e-4f * fe;
+    y = y + t;
+    t = -0.5f * z;
+    y = y + t;
+    t = m + y;
+    z = 0.693359375f * fe;
+    return t + z;
+}
 
 static float gumbel_f32(uint32_t bits) {
     const float tiny = 1.17549435e-38f;
     volatile float f = uniform_f32(bits) * 1.0f + tiny;
     float u = f > tiny ? f : tiny;
-    return -log_f32(-log_f32(u));
+    return -log_f32_poly(-log_f32_poly(u));
 }
 
 static int categorical4(const uint32_t key[2], const float logits[4], int mode) {

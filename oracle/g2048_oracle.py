@@ -22,9 +22,10 @@ board-frames derived from the reference's own assets (``assets/2048_drul_actions
 frames, ``assets/2048_random_actions.svg`` 123x4 frames, legacy threefry stream) and against the
 1000-episode max-tile histograms published in the reference README (partitionable stream).
 
-One deliberate restatement choice: the two ``log`` calls of the Gumbel draw are evaluated as
-``float32(log(float64(x)))`` (a correctly rounded f32 log for all practical purposes) so that
-the C oracle, this oracle and the HIP kernels agree bit-for-bit with each other.
+One deliberate restatement choice: the two ``log`` calls of the Gumbel draw (jax: XLA's f32 log) are
+evaluated with a fixed f32 polynomial in individually rounded IEEE mul/add (``_log_f32_poly``) so that
+the C oracle, this oracle and the HIP kernels agree bit-for-bit with each other; the reference's assets
+are still reproduced exactly with it.
 """
 from __future__ import annotations
 
@@ -124,14 +125,41 @@ def uniform_f32(bits: np.ndarray) -> np.ndarray:
 
 
 def _log_f32(x: np.ndarray) -> np.ndarray:
+    """Correctly rounded f32 log (via f64): where the reference takes log(1/n) in act_randomly."""
     return np.log(x.astype(np.float64)).astype(np.float32)
+
+
+_LOG_P = [np.float32(c) for c in (7.0376836292E-2, -1.1514610310E-1, 1.1676998740E-1, -1.2420140846E-1,
+                                  1.4249322787E-1, -1.6668057665E-1, 2.0000714765E-1, -2.4999993993E-1,
+                                  3.3333331174E-1)]
+
+
+def _log_f32_poly(x: np.ndarray) -> np.ndarray:
+    """f32 log in pure IEEE f32 mul/add (Cephes logf polynomial), operation-for-operation the same as
+    oracle/g2048_oracle.c:log_f32_poly and the HIP kernels' log_f32 (used for the Gumbel noise)."""
+    x = np.asarray(x, np.float32)
+    bits = x.view(U32)
+    e = ((bits >> U32(23)) & U32(0xFF)).astype(np.int32) - 126
+    m = ((bits & U32(0x007FFFFF)) | U32(0x3F000000)).view(np.float32)
+    small = m < np.float32(0.707106781186547524)
+    e = np.where(small, e - 1, e)
+    m = np.where(small, (m + m) + np.float32(-1.0), m + np.float32(-1.0)).astype(np.float32)
+    z = m * m
+    y = np.full_like(m, _LOG_P[0])
+    for c in _LOG_P[1:]:
+        y = y * m + c  # numpy rounds the product and the sum separately (no FMA)
+    y = (y * m) * z
+    fe = e.astype(np.float32)
+    y = y + np.float32(-2.12194440e-4) * fe
+    y = y + np.float32(-0.5) * z
+    return ((m + y) + np.float32(0.693359375) * fe).astype(np.float32)
 
 
 def gumbel_f32(bits: np.ndarray) -> np.ndarray:
     """jax.random.gumbel from raw bits: -log(-log(u)), u in [tiny, 1)."""
     f = uniform_f32(bits)
     u = np.maximum(_F32_TINY, f * np.float32(1.0) + _F32_TINY)
-    return -_log_f32(-_log_f32(u))
+    return -_log_f32_poly(-_log_f32_poly(u))
 
 
 def categorical4(keys: np.ndarray, logits: np.ndarray, mode: int) -> np.ndarray:

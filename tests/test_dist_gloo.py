@@ -1,0 +1,95 @@
+"""The N>1 path on CPU: two gloo ranks exercise the trainer's sharding rule, flat-gradient all-reduce and the
+global z-score statistics.  (The env shard-invariance itself is a -m gpu test: test_gpu_kernels.py.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, results):
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, os.path.join(root, "2048-ppo-agent_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from src.ppo.data_loader import zscore
+        from src.ppo.ppo_agent import MLPAgent
+        from src.ppo.ppo_trainer import PPOTrainer
+        from src.ppo.rollout_buffer import RolloutBuffer
+
+        torch.manual_seed(100 + rank)  # different initial weights per rank: the trainer must broadcast rank 0's
+        agent = MLPAgent(hidden_dim=16, trunk_dim=16)
+        optim = dict(opt_name="adamw", max_lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,
+                     warmup_steps_ratio=0.1, scheduler_names=["constant", "constant"],
+                     blacklist_weight_modules=["norm", "embedding"])
+        tr = PPOTrainer(agent, None, RolloutBuffer(31, 16, 4), optim, max_steps=10, device=torch.device("cpu"),
+                        mixed_precision=None, use_action_mask=True)
+        assert tr.world == world and tr.rank == rank
+        assert tr._shard(8) == (4, 4 * rank, 8)
+        try:
+            tr._shard(7)
+            raise AssertionError("indivisible batch must be rejected")
+        except ValueError:
+            pass
+        w0 = torch.cat([p.detach().flatten() for p in agent.parameters()])
+        gathered = [torch.zeros_like(w0) for _ in range(world)]
+        dist.all_gather(gathered, w0)
+        assert all(torch.equal(g, gathered[0]) for g in gathered), "parameters not broadcast"
+
+        g = torch.Generator().manual_seed(7)  # the same full batch on every rank
+        M = 12
+        boards = torch.randint(0, 10, (M, 16), generator=g, dtype=torch.uint8)
+        actions = torch.randint(0, 4, (M,), generator=g)
+        masks = torch.ones(M, 4, dtype=torch.bool)
+        old_lp = -torch.rand(M, generator=g)
+        adv = torch.randn(M, generator=g)
+        ret = torch.randn(M, generator=g)
+        agent.eval()
+        # single-process answer: full-batch gradient
+        ref = MLPAgent(hidden_dim=16, trunk_dim=16).eval()
+        ref.load_state_dict(agent.state_dict())
+        tr_ref = PPOTrainer.__new__(PPOTrainer)
+        tr_ref.agent, tr_ref.clip_epsilon, tr_ref.value_loss_coef, tr_ref.entropy_coef = ref, 0.2, 0.5, 0.01
+        tr_ref.use_action_mask = True
+        tr_ref._compute_ppo_loss(boards, actions, masks, old_lp, adv, ret)[0].backward()
+        want = torch.cat([p.grad.flatten() for p in ref.parameters()])
+        # sharded: each rank takes its half, one all-reduce of the flat bucket
+        sl = slice(rank * M // world, (rank + 1) * M // world)
+        tr._zero_grad()
+        tr._compute_ppo_loss(boards[sl], actions[sl], masks[sl], old_lp[sl], adv[sl], ret[sl])[0].backward()
+        tr._allreduce_grads()
+        got = torch.cat([p.grad.flatten() for p in agent.parameters()])
+        assert torch.equal(got, tr._flat_grad), "p.grad must alias the flat bucket"
+        np.testing.assert_allclose(got.numpy(), want.numpy(), atol=1e-6, rtol=1e-5)
+
+        # global z-score == single-process z-score of the concatenation
+        full = torch.randn(101, generator=g) * 3 + 1
+        bounds = [0, 37, 101]
+        mine = zscore(full[bounds[rank]:bounds[rank + 1]], dist.group.WORLD)
+        want_z = (full - full.mean()) / (full.std() + 1e-8)
+        np.testing.assert_allclose(mine.numpy(), want_z[bounds[rank]:bounds[rank + 1]].numpy(), atol=1e-5, rtol=1e-5)
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}

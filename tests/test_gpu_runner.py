@@ -1,0 +1,205 @@
+"""BatchRunner / act_fn plug-ins on the GPU: the reference's own test expectations (tests/runs/*, tests/actions/*,
+tests/integration/*) re-expressed against the drop-in API, plus whole-episode parity with the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as orc
+from oracle import g2048_oracle as npo
+from src.actions import act_drul, act_randomly
+from src.ppo import PPOAgent, TorchActionFunction
+from src.runs import BatchRunner, run_actions_batch, run_actions_max_tile
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def mock_act_fn(key, obs, mask):
+    """The reference's test plug-in ignores the mask (tests/runs/test_batch_runner.py:12-16): illegal moves occur."""
+    r = np.random.default_rng(int(key[0]) ^ int(key[1]))
+    return r.integers(0, 4), np.float32(r.normal()), np.float32(r.normal())
+
+
+def test_init_and_act_fn_property(dev):
+    r = BatchRunner(init_seed=0, act_fn=None)
+    assert r.act_fn is None
+    with pytest.raises(ValueError, match="The action function is not set"):
+        r.run_actions_batch(4)
+    r.act_fn = act_drul
+    assert r.act_fn is not None
+    with pytest.raises((ValueError, RuntimeError)):
+        r.run_actions_batch(0)
+
+
+@pytest.mark.parametrize("batch_size", [2, 5, 10])
+def test_run_actions_batch_shapes_host_callable(dev, batch_size):
+    out = BatchRunner(init_seed=0, act_fn=mock_act_fn).run_actions_batch(batch_size)
+    obs, actions, masks, lps, values, rewards, terms = out
+    assert all(isinstance(a, np.ndarray) for a in out)
+    T = obs.shape[1]
+    assert obs.shape == (batch_size, T, 4, 4, 31) and obs.dtype == bool
+    assert actions.shape == (batch_size, T) and masks.shape == (batch_size, T, 4)
+    assert lps.shape == values.shape == rewards.shape == terms.shape == (batch_size, T)
+    assert terms[:, -1].all()
+    assert ((actions >= 0) & (actions <= 3)).all()
+    assert (obs.sum(-1) == 1).all()  # one-hot
+    assert (rewards == -1).any()  # mask-ignoring policy -> illegal move -> terminate with -1
+
+
+def test_determinism_and_stream_continuation(dev):
+    a = BatchRunner(init_seed=0, act_fn=act_randomly).run_actions_batch(8)
+    b = BatchRunner(init_seed=0, act_fn=act_randomly).run_actions_batch(8)
+    for x, y in zip(a, b):
+        assert (x is None and y is None) or np.array_equal(x, y)
+    r = BatchRunner(init_seed=0, act_fn=act_randomly)
+    first = r.run_actions_batch(8)
+    second = r.run_actions_batch(8)  # the key chain persists across calls
+    assert not np.array_equal(first[0][:, 0], second[0][:, 0])
+    c = BatchRunner(init_seed=1, act_fn=act_randomly).run_actions_batch(8)
+    assert not np.array_equal(a[0][:, 0], c[0][:, 0])
+
+
+@pytest.mark.parametrize("mode", ["legacy", "partitionable"])
+@pytest.mark.parametrize("policy", ["drul", "random"])
+def test_seven_tuple_equals_numpy_oracle(dev, mode, policy):
+    B = 33
+    m = 0 if mode == "legacy" else 1
+    want = npo.Runner(5, m).run(B, policy)
+    r = BatchRunner(init_seed=5, act_fn=act_drul if policy == "drul" else act_randomly, rng_mode=mode)
+    obs, actions, masks, lps, values, rewards, terms = r.run_actions_batch(B)
+    assert (obs == npo.observation(want["boards"].reshape(-1, 16)).reshape(obs.shape)).all()
+    assert (actions == want["actions"]).all() and (masks == want["masks"]).all()
+    assert (rewards == want["rewards"]).all() and (terms == want["terms"]).all()
+    assert values is None
+    if policy == "random":
+        assert (lps == want["log_probs"]).all()
+    else:
+        assert lps is None
+    ref_runner = npo.Runner(5, m)
+    ref_runner.run(B, policy)
+    assert (r.key == ref_runner.key).all()  # the host key chain advanced exactly as the reference's
+
+
+def test_golden_animation_through_public_api(dev):
+    """assets/2048_{drul,random}_actions.svg were produced by run_actions_batch(0, 4, act_fn) (legacy stream)."""
+    for name, fn in (("drul", act_drul), ("random", act_randomly)):
+        g = np.load(os.path.join(G, f"svg_{name}_seed0_b4.npy"))
+        states = run_actions_batch(0, 4, fn, rng_mode="legacy")
+        assert len(states) == g.shape[0]
+        for k, s in enumerate(states):
+            assert (s.board == g[k]).all()
+            assert (s.observation.argmax(-1).reshape(4, 16) == g[k]).all()
+        assert states[-1].terminated.all()
+
+
+@pytest.mark.parametrize("name,fn", [("drul", act_drul), ("random", act_randomly)])
+def test_readme_histogram_protocol(dev, name, fn):
+    """run/viz_naive_strategies.py:158-171 -- 10 x BatchRunner(42 + 100 i).run_rollout_batch(100), final max tile."""
+    want = json.load(open(os.path.join(G, "readme_histograms.json")))[f"{name}_percent"]
+    tiles = []
+    for i in range(10):
+        states = BatchRunner(init_seed=42 + 100 * i, act_fn=fn).run_rollout_batch(100)
+        final = states[-1].observation.argmax(-1).reshape(100, 16)
+        tiles += (2 ** final.max(1)).tolist()
+    vals, counts = np.unique(tiles, return_counts=True)
+    assert {str(int(v)): round(100.0 * c / 1000, 1) for v, c in zip(vals, counts)} == want
+
+
+def test_run_rollout_batch_states(dev):
+    states = BatchRunner(init_seed=3, act_fn=act_drul).run_rollout_batch(6)
+    assert not states[0].terminated.any() and states[0].rewards.shape == (6, 1)
+    assert states[0].legal_action_mask.shape == (6, 4) and states[0].observation.shape == (6, 4, 4, 31)
+    assert (states[0].board > 0).sum(1).tolist() == [2] * 6  # two spawned tiles
+    assert states[-1].terminated.all() and not states[-2].terminated.all()
+
+
+def test_run_actions_max_tile(dev):
+    stats = run_actions_max_tile(init_seed=0, batch_size=10, num_envs=35, act_fn=act_drul)
+    assert int(stats.num_samples[0, 0]) == 30  # rounded down to a multiple of the batch size
+    assert 32 <= float(stats.mean[0, 0]) <= 512
+
+
+def test_act_fn_plugins_unbatched_protocol(dev):
+    obs = np.zeros((4, 4, 31), bool)
+    mask = np.array([True, False, True, False])
+    a, lp, v = act_drul(np.array([0, 0], np.uint32), obs, mask)
+    assert int(a) == 2 and lp is None and v is None  # first legal of [3, 2, 1, 0]
+    for seed in range(20):
+        a, lp, v = act_randomly(npo.key(seed), obs, mask)
+        assert int(a) in (0, 2) and np.isclose(lp, np.log(0.5)) and v is None
+    keys = orc.split(npo.key(0), 100, 1)
+    masks = np.random.default_rng(0).random((100, 4)) > 0.5
+    a, lp, v = act_randomly(keys, np.zeros((100, 4, 4, 31), bool), masks)  # vmapped form
+    assert a.shape == (100,) and np.isfinite(lp).all()
+    assert all(masks[i, a[i]] or not masks[i].any() for i in range(100))
+    a, _, _ = act_drul(keys, np.zeros((10, 4, 4, 31), bool), masks[:10])
+    assert a.shape == (10,)
+    with pytest.raises(AssertionError):
+        act_drul(None, np.zeros((4, 4, 30)), mask)
+
+
+def _small_agent(seed=0):
+    torch.manual_seed(seed)
+    return PPOAgent(hidden_dim=32, d_model=32, nhead=4, num_layers=1, dim_feedforward=64, dropout=0.0,
+                    reduction="cls")
+
+
+def test_torch_action_function_attributes_and_consistency(dev):
+    agent = _small_agent()
+    w = TorchActionFunction(agent, use_mask=True, device=dev)
+    assert w.device == dev and isinstance(w._agent_state, dict) and w.use_mask and w.sample_actions
+    assert not agent.training  # side effect of the reference: eval mode
+    rng = np.random.default_rng(0)
+    boards = rng.integers(0, 8, size=(64, 16)).astype(np.uint8)
+    obs = npo.observation(boards)
+    masks = rng.random((64, 4)) > 0.4
+    masks[:, 1] = True
+    keys = orc.split(npo.key(1), 64, 1)
+    a, lp, v = w(keys, obs, masks)
+    assert all(masks[i, a[i]] for i in range(64))  # mask respected
+    with torch.no_grad():
+        x = torch.from_numpy(obs.reshape(64, 16, 31)).float().to(dev)
+        elp, ev, _ = agent.evaluate_actions(x, torch.from_numpy(a).long().to(dev), torch.from_numpy(masks).to(dev))
+    # reference tests/ppo/test_log_prob_consistency.py: wrapper log-prob/value == evaluate_actions within 1e-5
+    np.testing.assert_allclose(lp, elp.cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(v, ev.flatten().cpu().numpy(), atol=1e-5)
+    # un-batched call and argmax mode
+    a1, lp1, v1 = w(keys[0], obs[0], masks[0])
+    assert int(a1) == a[0] and np.isclose(lp1, lp[0], atol=1e-6)
+    wa = TorchActionFunction(agent, use_mask=True, sample_actions=False, device=dev)
+    aa, _, _ = wa(keys, obs, masks)
+    with torch.no_grad():
+        ml, _ = agent(x, torch.from_numpy(masks).to(dev))
+    assert (aa == ml.argmax(-1).cpu().numpy()).all()
+    only = np.zeros((64, 4), bool)
+    only[:, 3] = True
+    a3, _, _ = w(keys, obs, only)
+    assert (a3 == 3).all()  # single legal action
+
+
+def test_policy_rollout_through_runner(dev):
+    agent = _small_agent(1)
+    r = BatchRunner(init_seed=0, act_fn=TorchActionFunction(agent, use_mask=True, device=dev))
+    obs, actions, masks, lps, values, rewards, terms = r.run_actions_batch(16)
+    assert terms[:, -1].all() and np.isfinite(lps).all() and np.isfinite(values).all()
+    assert (rewards > 0).any() and (rewards >= 0).all()  # masked policy never plays an illegal move
+    assert np.take_along_axis(masks, actions[..., None], 2).all()
+    r2 = BatchRunner(init_seed=0, act_fn=TorchActionFunction(agent, use_mask=True, device=dev))
+    again = r2.run_actions_batch(16)
+    assert np.array_equal(again[1], actions) and np.array_equal(again[5], rewards)  # deterministic
+    # the trajectory equals an oracle replay driven by the same logits (env + sampling parity end to end)
+    tr = BatchRunner(init_seed=0, act_fn=TorchActionFunction(agent, use_mask=True, device=dev)).collect(16, fill_frozen=True)
+    _, subs = orc.chain(npo.key(0), 1 + 2 * tr.T, 1)
+    b, m, d = orc.init(orc.split(subs[0], 16, 1), 1)
+    with torch.no_grad():
+        for t in range(tr.T):
+            assert (tr.boards[t].cpu().numpy() == b).all()
+            logits, _ = agent(torch.from_numpy(b).to(dev), None)
+            a, lp = orc.act_logits(orc.split(subs[1 + 2 * t], 16, 1), logits.float().cpu().numpy(), m, 1, 1, 1)
+            assert (tr.actions[t].cpu().numpy() == a).all()
+            b, m, d, rw = orc.step(b, m, d, a, orc.split(subs[2 + 2 * t], 16, 1), 1)
+            assert (tr.rewards[t].cpu().numpy() == rw).all()
+    assert d.all()

@@ -1,0 +1,188 @@
+"""Host-side (pure torch / numpy) pieces of the drop-in API against vectors produced by the reference itself
+(tests/golden/torch_reference.npz, made by tests/golden/make_golden_torch.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from src.env_definitions import ACTION_DIM, BOARD_DIM, BOARD_FLAT_DIM, OBS_DIM
+from src.optim import Lamb, configure_bert_optimizers
+from src.optim.configure_optimizers import split_decay_groups
+from src.ppo.ppo_agent import MLPAgent, PPOAgent
+from src.ppo.ppo_trainer import PPOTrainer, _History
+from src.ppo.rollout_buffer import RolloutBuffer
+from src.ppo.transformer_encoder import PositionalEncoding2D, TransformerEncoder, get_emb
+from src.stats import RunningStatsVec
+
+REF = np.load(os.path.join(os.path.dirname(__file__), "golden", "torch_reference.npz"))
+SMALL = dict(observation_dim=31, action_dim=4, hidden_dim=48, d_model=32, nhead=4, num_layers=2, dim_feedforward=64,
+             dropout=0.1)
+
+
+def _agent(red):
+    agent = PPOAgent(reduction=red, **SMALL).eval()
+    sd = {k[len(f"agent_{red}/sd/"):]: torch.from_numpy(REF[k]) for k in REF.files if k.startswith(f"agent_{red}/sd/")}
+    assert set(sd) == set(agent.state_dict())  # same parameter AND buffer names as the reference
+    agent.load_state_dict(sd)
+    return agent
+
+
+def test_constants():
+    assert (OBS_DIM, BOARD_DIM, BOARD_FLAT_DIM, ACTION_DIM) == (31, (4, 4), 16, 4)
+
+
+@pytest.mark.parametrize("red", ["cls", "mean"])
+def test_agent_matches_reference_forward(red):
+    agent = _agent(red)
+    boards = torch.from_numpy(REF[f"agent_{red}/boards"])
+    obs = torch.nn.functional.one_hot(boards.long(), 31).float()
+    masks = torch.from_numpy(REF[f"agent_{red}/masks"])
+    actions = torch.from_numpy(REF[f"agent_{red}/actions"])
+    with torch.no_grad():
+        for x in (obs, boards):  # reference one-hot layout and the packed-board fast path
+            logits, values = agent(x, None)
+            np.testing.assert_allclose(logits.numpy(), REF[f"agent_{red}/logits"], atol=1e-5, rtol=1e-5)
+            np.testing.assert_allclose(values.numpy(), REF[f"agent_{red}/values"], atol=1e-5, rtol=1e-5)
+            ml, _ = agent(x, masks)
+            np.testing.assert_allclose(ml.numpy(), REF[f"agent_{red}/masked_logits"], atol=1e-5, rtol=1e-5)
+            lp, v, ent = agent.evaluate_actions(x, actions, masks)
+            np.testing.assert_allclose(lp.numpy(), REF[f"agent_{red}/eval_logp"], atol=1e-5, rtol=1e-5)
+            np.testing.assert_allclose(ent.numpy(), REF[f"agent_{red}/eval_entropy"], atol=1e-5, rtol=1e-5)
+
+
+def test_pe_buffer_equals_reference_buffer():
+    pe = PositionalEncoding2D(4, 4, 32).pe
+    np.testing.assert_allclose(pe.numpy(), REF["agent_cls/sd/transformer.positional_encoding.pe"], atol=1e-7)
+    e = get_emb(torch.tensor([[0.0, 1.0]]))
+    np.testing.assert_allclose(e.numpy(), [[0.0, 1.0, np.sin(1.0), np.cos(1.0)]], atol=1e-7)
+
+
+def test_default_agent_size_and_state_dict_families():
+    agent = PPOAgent(hidden_dim=512, d_model=256, nhead=8, num_layers=4, dim_feedforward=1024, reduction="cls")
+    assert sum(p.numel() for p in agent.parameters()) == 3958272
+    keys = set(agent.state_dict())
+    for k in ("input_embedding.weight", "transformer.cls_token", "transformer.positional_encoding.inv_freq",
+              "transformer.positional_encoding.pe", "transformer.encoder.layers.3.self_attn.in_proj_weight",
+              "transformer.encoder.layers.0.norm2.bias", "actor.4.weight", "critic.0.bias"):
+        assert k in keys
+    assert agent.state_dict()["transformer.positional_encoding.pe"].shape == (1, 4, 4, 256)
+
+
+def test_agent_behaviour():
+    agent = _agent("cls")
+    obs = torch.nn.functional.one_hot(torch.randint(0, 12, (7, 16)), 31).float()
+    mask = torch.zeros(7, 4, dtype=torch.bool)
+    mask[:, 2] = True
+    a, lp, v = agent.get_action(obs, mask)
+    assert (a == 2).all() and a.shape == (7,) and v.shape == (7, 1)  # single legal action is forced
+    lp2, v2, ent = agent.evaluate_actions(obs, a, mask)
+    np.testing.assert_allclose(lp.detach().numpy(), lp2.detach().numpy(), atol=1e-6)
+    with pytest.raises(RuntimeError):
+        agent(torch.zeros(2, 16, 30))  # wrong observation dim
+    with pytest.raises(ValueError):
+        TransformerEncoder(32, 4, 1, 64)(torch.zeros(1, 16, 32), reduction="max")
+    m = MLPAgent(hidden_dim=32, trunk_dim=24).eval()
+    boards = torch.randint(0, 12, (5, 16), dtype=torch.uint8)
+    l1, v1 = m(boards)
+    l2, v2 = m(torch.nn.functional.one_hot(boards.long(), 31).float())
+    np.testing.assert_allclose(l1.detach().numpy(), l2.detach().numpy(), atol=1e-5)
+
+
+def test_ppo_loss_matches_reference():
+    agent = _agent("mean")
+    tr = PPOTrainer.__new__(PPOTrainer)
+    tr.agent, tr.clip_epsilon, tr.value_loss_coef, tr.entropy_coef, tr.use_action_mask = agent, 0.2, 0.5, 0.01, True
+    boards = torch.from_numpy(REF["agent_mean/boards"])
+    t = lambda k: torch.from_numpy(REF[k])
+    with torch.no_grad():
+        loss, pl, vl, el, nlp = tr._compute_ppo_loss(boards, t("agent_mean/actions"), t("agent_mean/masks"),
+                                                    t("loss/old_logp"), t("loss/adv"), t("loss/ret"))
+    for got, key in ((loss, "total"), (pl, "policy"), (vl, "value"), (el, "entropy"), (nlp, "new_logp")):
+        np.testing.assert_allclose(got.numpy(), REF[f"loss/{key}"], atol=1e-5, rtol=1e-5)
+
+
+def test_rollout_buffer_numpy_interface_matches_reference():
+    buf = RolloutBuffer(31, 16, 4)
+    buf.store_batch(REF["buffer/in_obs"], REF["buffer/in_act"], REF["buffer/in_msk"], REF["buffer/in_rew"],
+                    REF["buffer/in_val"], REF["buffer/in_lp"], REF["buffer/in_term"])
+    assert buf.buffer_size == int(REF["buffer/size"]) == 20
+    got = buf.get_buffer_data()
+    for k in ("observations", "actions", "action_masks", "rewards", "values", "log_probs", "terminations"):
+        assert got[k].dtype == REF[f"buffer/out_{k}"].dtype
+        assert got[k].shape == REF[f"buffer/out_{k}"].shape
+        assert (got[k] == REF[f"buffer/out_{k}"]).all()
+    buf.store_batch(REF["buffer/in_obs"], REF["buffer/in_act"], REF["buffer/in_msk"], REF["buffer/in_rew"],
+                    REF["buffer/in_val"], REF["buffer/in_lp"], REF["buffer/in_term"])
+    assert buf.buffer_size == 40 and len(buf.get_buffer_data()["rewards"]) == 40
+    buf.reset()
+    assert buf.buffer_size == 0 and buf.get_buffer_data()["rewards"].shape == (0,)
+
+
+def test_rollout_buffer_validation_errors():
+    buf = RolloutBuffer(observation_dim=4, observation_length=5, action_dim=2)
+    with pytest.raises(ValueError) as e:
+        buf._validate_and_reshape_observations(np.zeros((3, 4, 15), np.float32))
+    assert "Cannot reshape observations" in str(e.value)
+    assert "15 elements per timestep but expected 20 elements" in str(e.value)
+    with pytest.raises(ValueError) as e:
+        buf._validate_and_reshape_observations(np.zeros(10, np.float32))
+    assert "Observations must have at least 2 dimensions" in str(e.value) and "but got shape (10,)" in str(e.value)
+    assert buf._validate_and_reshape_observations(np.zeros((3, 4, 20))).shape == (3, 4, 5, 4)
+    buf2 = RolloutBuffer(3, (4, 4), 2)
+    assert buf2._validate_and_reshape_observations(np.zeros((2, 3, 48))).shape == (2, 3, 4, 4, 3)
+
+
+def test_weight_decay_groups_match_reference():
+    agent = PPOAgent(hidden_dim=512, d_model=256, nhead=8, num_layers=4, dim_feedforward=1024, reduction="cls")
+    decay, no_decay = split_decay_groups(agent, ["norm", "embedding"])
+    assert decay == REF["optim/decay_names"].tolist() and no_decay == REF["optim/no_decay_names"].tolist()
+    assert "transformer.cls_token" in decay and "input_embedding.weight" in no_decay
+    d = configure_bert_optimizers(agent, "adamw", 4e-4, (0.9, 0.999), 1e-6, 0.01, 1000, 0.025,
+                                  ["constant", "constant"], ["norm", "embedding"])
+    g = d["optimizer"].param_groups
+    assert [(len(x["params"]), sum(p.numel() for p in x["params"]), x["weight_decay"]) for x in g] == \
+        [(23, 3934976, 0.01), (37, 23296, 0.0)]
+    assert d["lr_scheduler"]["interval"] == "step"
+    with pytest.raises(TypeError):
+        configure_bert_optimizers(agent, "sgd", 1e-3, (0.9, 0.999), 1e-6, 0.0, 10, 0.1, ["linear", "cosine"])
+    for names in (["linear", "linear"], ["linear", "cosine"], ["constant", "constant"]):
+        d = configure_bert_optimizers(torch.nn.Linear(3, 3), "lamb", 1e-3, (0.9, 0.999), 1e-6, 0.01, 100, 0.1, names)
+        d["optimizer"].step()
+        for _ in range(20):
+            d["lr_scheduler"]["scheduler"].step()
+
+
+def test_lamb_matches_reference_steps():
+    w = torch.nn.Parameter(torch.from_numpy(REF["lamb/w0"].copy()))
+    b = torch.nn.Parameter(torch.from_numpy(REF["lamb/b0"].copy()))
+    opt = Lamb([{"params": [w], "weight_decay": 0.01}, {"params": [b], "weight_decay": 0.0}], lr=1e-2)
+    for gw, gb in zip(REF["lamb/gw"], REF["lamb/gb"]):
+        w.grad, b.grad = torch.from_numpy(gw.copy()), torch.from_numpy(gb.copy())
+        opt.step()
+    np.testing.assert_allclose(w.detach().numpy(), REF["lamb/w2"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(b.detach().numpy(), REF["lamb/b2"], atol=1e-6, rtol=1e-5)
+
+
+def test_running_stats_vec():
+    rng = np.random.default_rng(0)
+    xs = [rng.normal(size=(3, n)) for n in (5, 1, 17)]
+    s = RunningStatsVec()
+    assert s.mean == 0.0 and s.std == 0.0
+    for x in xs:
+        s.push(x)
+    full = np.concatenate(xs, axis=1)
+    np.testing.assert_allclose(s.mean[:, 0], full.mean(1))
+    np.testing.assert_allclose(s.variance[:, 0], full.var(1))
+    np.testing.assert_allclose(s.std[:, 0], full.std(1))
+    assert s.num_samples[:, 0].tolist() == [23, 23, 23]
+    with pytest.raises(ValueError):
+        s.push(np.zeros(3))
+    s.clear()
+    assert s.mean == 0.0
+
+
+def test_history_slices_like_a_list():
+    h = _History(maxlen=5)
+    h.extend(range(8))
+    assert h[-3:] == [5, 6, 7] and h[0] == 3 and len(h) == 5
