@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the 2048 rollout + PPO engine on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL)
+
+Workload (BASELINE.json configs[2] at N=1, configs[3] at N=8): 65 536 parallel boards PER GPU, the reference's
+default Transformer policy (3.96 M parameters) in bf16, random-init weights, boards generated on the device by
+self-play from seed 0.  One "step" = one complete PPO iteration: lock-step rollout of 65 536 x N complete
+episodes with the policy in the loop (fused sample + board step + trajectory write), HIP compaction + GAE scan,
+then the clipped-surrogate update (5 epochs x up to 300 000 samples, minibatch 2048, AdamW, grad-clip, one flat
+gradient all-reduce per minibatch when N > 1) -- the reference's configs/trainer/default.yaml.
+`value` = live env-steps gathered by all ranks in the K timed steps / wall time (max over ranks).
+
+Also on the JSON line:
+  roofline      the board-step kernel (g2048_step, 50 algorithmic bytes per env-step) at a saturating launch of
+                2^24 boards, timed with HIP events on its launch stream
+  in_loop       the fused policy-step kernel as it ran inside the timed region (HIP events around every launch)
+  env_only      fused random-policy rollout of the same 65 536 boards (no network): env-steps/sec
+  cpu_baseline  the C oracle (OpenMP, all host cores) on a bounded sample of random-policy episodes (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "2048-ppo-agent_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling is ~6290 GB/s
+STEP_BYTES = 50  # board 16 r + 16 w, action 4, key 8, reward 4, mask 1, done 1
+POLICY_STEP_BYTES = 93  # fused policy step: state 18 r + 18 w (+ ep_len 4 r/w), logits 16, value 4, trajectory 29
+
+TRAINER_CFG = dict(gamma=0.99, lambda_gae=0.95, clip_epsilon=0.2, value_loss_coef=0.5, entropy_coef=0.01,
+                   max_grad_norm=0.5, target_kl=0.25, use_action_mask=True, mixed_precision="bfloat16",
+                   max_samples_per_epoch=300000, shuffle_on_reset=True)
+OPTIM_CFG = dict(opt_name="adamw", max_lr=4e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,
+                 warmup_steps_ratio=0.025, scheduler_names=["constant", "constant"],
+                 blacklist_weight_modules=["norm", "embedding"])
+MODEL_CFG = dict(observation_dim=31, action_dim=4, hidden_dim=512, d_model=256, nhead=8, num_layers=4,
+                 dim_feedforward=1024, dropout=0.1, reduction="cls")
+
+
+def step_kernel_roofline(dev, boards_per_launch: int, launches: int = 20):
+    """g2048_step at a saturating size, HIP events on the stream it is launched on."""
+    from src.g2048 import native as nv
+
+    B = boards_per_launch
+    boards = torch.empty((B, 16), dtype=torch.uint8, device=dev)
+    masks = torch.empty(B, dtype=torch.uint8, device=dev)
+    done = torch.empty(B, dtype=torch.uint8, device=dev)
+    ep = torch.empty(B, dtype=torch.int32, device=dev)
+    rew = torch.empty(B, dtype=torch.float32, device=dev)
+    nv.reset_fused((1, 2), boards, masks, done, ep, B, 0, nv.RNG_PARTITIONABLE)
+    keys = nv.split((5, 6), B, nv.RNG_PARTITIONABLE, dev)
+    actions = torch.empty(B, dtype=torch.int32, device=dev)
+    # mid-game boards: 24 steps of the DRUL policy (always legal), then time steps with legal actions
+    for _ in range(24):
+        nv.act_drul(masks, actions)
+        nv.step(boards, masks, done, actions, keys, rew, nv.RNG_PARTITIONABLE)
+    nv.act_drul(masks, actions)
+    live = float((done == 0).float().mean().item())
+    stream = torch.cuda.current_stream()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record(stream)
+    for _ in range(launches):
+        nv.step(boards, masks, done, actions, keys, rew, nv.RNG_PARTITIONABLE)
+    end.record(stream)
+    torch.cuda.synchronize()
+    us = start.elapsed_time(end) * 1e3 / launches
+    gbs = STEP_BYTES * B / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_step (g2048_step)",
+            "boards_per_launch": B, "launch_us": round(us, 2), "algorithmic_bytes_per_env_step": STEP_BYTES,
+            "live_fraction": round(live, 3)}
+
+
+class _TimedPolicyStep:
+    """Wraps native.policy_step with HIP events on the launch stream to time the kernel inside the timed region."""
+
+    def __init__(self, nv):
+        self.nv, self.orig, self.events, self.on = nv, nv.policy_step, [], False
+
+    def __call__(self, *a, **k):
+        if not self.on:
+            return self.orig(*a, **k)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream()
+        s.record(st)
+        self.orig(*a, **k)
+        e.record(st)
+        self.events.append((s, e))
+
+    def mean_us(self):
+        return float(np.mean([s.elapsed_time(e) for s, e in self.events])) * 1e3 if self.events else None
+
+
+def cpu_baseline(boards: int, target_seconds: float = 12.0):
+    """C oracle, OpenMP over boards, random policy, whole episodes; bounded sample."""
+    from oracle import c_oracle as orc
+    from oracle import g2048_oracle as npo
+
+    orc.rollout(npo.key(99), 1024, 0, 1024, 1, 1)  # warm (build, page-in)
+    t0 = time.time()
+    steps, reps = 0, 0
+    while time.time() - t0 < target_seconds and reps < 64:
+        steps += orc.rollout(npo.key(reps), boards, 0, boards, 1, 1)["total_steps"]
+        reps += 1
+    dt = time.time() - t0
+    return {"value": round(steps / dt, 1), "unit": "env-steps/sec", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{reps} x {boards} random-policy episodes ({steps} env-steps), env + RNG + policy draw only "
+                      f"(no policy network), C restatement of the Pgx 2048 env (oracle/g2048_oracle.c), "
+                      f"{dt:.1f} s on {os.cpu_count()} host CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--boards", type=int, default=65536, help="parallel boards per GPU")
+    ap.add_argument("--train-batch", type=int, default=2048)
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--roofline-boards", type=int, default=1 << 24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from src.actions import act_randomly
+    from src.g2048 import native as nv
+    from src.ppo import PPOAgent, PPOTrainer, RolloutBuffer
+    from src.runs import BatchRunner
+
+    timed = _TimedPolicyStep(nv)
+    nv.policy_step = timed
+    torch.manual_seed(0)
+    agent = PPOAgent(**MODEL_CFG)
+    runner = BatchRunner(init_seed=0, rng_mode="partitionable", device=dev)
+    trainer = PPOTrainer(agent, runner, RolloutBuffer(31, 16, 4), OPTIM_CFG, max_steps=500000, device=dev,
+                         rollout_amp=True, log_dir=os.path.join("/tmp", f"g2048_bench_logs_{rank}"), **TRAINER_CFG)
+    global_boards = args.boards * world
+
+    def one_step():
+        trainer.collect_rollouts(global_boards, 1)
+        n = trainer.last_rollout_stats["timesteps"]
+        trainer.update_policy(batch_size=args.train_batch, n_epochs=args.epochs)
+        return n
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    timed.on = True
+    t0 = time.perf_counter()
+    env_steps = 0
+    for _ in range(args.steps):
+        env_steps += one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    timed.on = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = {
+        "metric": "env-steps/sec at N parallel boards (full PPO loop: rollout with policy in the loop + GAE + update)",
+        "value": round(env_steps / elapsed, 1), "unit": "env-steps/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 boards / bf16 policy",
+        "data": "synthetic (self-play from seed 0, random-init policy weights)",
+        "config": {"workload": f"{args.boards} parallel boards per GPU, Transformer policy bf16 (3.96 M params), "
+                               f"full PPO iteration (BASELINE.json configs[2]; configs[3] when n_gpus=8)",
+                   "boards_per_gpu": args.boards, "global_boards": global_boards, "train_batch": args.train_batch,
+                   "update_epochs": args.epochs, "max_samples_per_epoch": TRAINER_CFG["max_samples_per_epoch"],
+                   "rng_mode": "partitionable", "parallelism": f"env-shard x{world} + 1 grad all-reduce/minibatch"},
+        "env_steps_per_ppo_iteration": int(env_steps / max(args.steps, 1)),
+    }
+    if rank == 0:
+        us = timed.mean_us()
+        if us:
+            live_per_launch = env_steps / world / max(len(timed.events), 1)
+            gbs = POLICY_STEP_BYTES * live_per_launch / (us * 1e-6) / 1e9
+            out["in_loop"] = {"kernel": "k_policy_step (g2048_policy_step)", "launches": len(timed.events),
+                              "launch_us": round(us, 2), "boards_per_launch": args.boards,
+                              "mean_live_boards_per_launch": round(live_per_launch, 1),
+                              "algorithmic_bytes_per_env_step": POLICY_STEP_BYTES, "achieved_GBps": round(gbs, 1),
+                              "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
+        out["roofline"] = step_kernel_roofline(dev, args.roofline_boards)
+        if not args.no_extras:
+            r = BatchRunner(init_seed=0, act_fn=act_randomly, rng_mode="partitionable", device=dev)
+            r.collect(args.boards)  # warm
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n = 0
+            for _ in range(5):
+                n += r.collect(args.boards).num_steps()
+            torch.cuda.synchronize()
+            out["env_only"] = {"value": round(n / (time.perf_counter() - t1), 1), "unit": "env-steps/sec",
+                               "what": f"fused random-policy rollout of {args.boards} boards, complete episodes, "
+                                       "trajectory written to HBM, no policy network"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.boards)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
