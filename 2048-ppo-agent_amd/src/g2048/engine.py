@@ -175,6 +175,13 @@ class RolloutEngine:
         bufs = self._alloc_traj(max(self.initial_capacity, sync_every), B, with_logp=True, with_values=True)
         cap = bufs["meta"].shape[0]
         live = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # Policy inference only on envs that are still running (refreshed at every poll): the lock-step batch
+        # keeps finished envs until the slowest one ends, but their logits are never used unless the caller
+        # wants the reference's frozen frames (fill_frozen), so they are not computed.
+        compact = not fill_frozen
+        live_idx = None
+        logits_full = torch.zeros((B, 4), dtype=torch.float32, device=self.device)
+        values_full = torch.zeros(B, dtype=torch.float32, device=self.device)
         t = 0
         while True:
             if t + sync_every > cap:
@@ -182,19 +189,28 @@ class RolloutEngine:
                 bufs = self._grow(bufs, t, cap)
             key, subs = nv.chain_keys(key, 2 * sync_every, self.rng_mode)
             for s in range(sync_every):
-                logits, values = policy_fn(boards, masks)
-                logits = logits.to(torch.float32).contiguous()
-                values = values.to(torch.float32).reshape(-1).contiguous()
+                if live_idx is None:
+                    logits, values = policy_fn(boards, masks)
+                    logits = logits.to(torch.float32).contiguous()
+                    values = values.to(torch.float32).reshape(-1).contiguous()
+                else:
+                    lg, vl = policy_fn(boards.index_select(0, live_idx), masks.index_select(0, live_idx))
+                    logits_full.index_copy_(0, live_idx, lg.to(torch.float32))
+                    values_full.index_copy_(0, live_idx, vl.to(torch.float32).reshape(-1))
+                    logits, values = logits_full, values_full
                 if s == sync_every - 1:
                     live.zero_()
                 nv.policy_step(subs[2 * s], subs[2 * s + 1], logits, values, use_mask, sample, t, boards, masks, done,
                                ep_len, bufs["boards"], bufs["meta"], bufs["rewards"], bufs["logp"], bufs["values"],
                                B_total, env0, fill_frozen, self.rng_mode, live)
                 t += 1
-            if int(live.item()) == 0:
+            n_live = int(live.item())
+            if n_live == 0:
                 break
             if t >= max_steps:
                 raise RuntimeError("rollout exceeded max_steps")
+            if compact and n_live < B:
+                live_idx = torch.nonzero(done == 0).flatten()
         return self._finish(bufs, state, init_boards, B, fill_frozen, key0, None)
 
 

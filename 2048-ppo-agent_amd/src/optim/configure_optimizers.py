@@ -61,15 +61,18 @@ def configure_bert_optimizers(model: torch.nn.Module, opt_name: str, max_lr: flo
         raise TypeError(f"Invalid optimizer name: {opt_name}")
     opt_cls = _OPTIMIZERS[opt_name]
     betas = tuple(betas)
+    extra = {}
+    if opt_name in ("adam", "adamw") and all(p.is_cuda for p in model.parameters()):
+        extra["fused"] = True  # one multi-tensor kernel per step, and GradScaler hands it found_inf without a sync
     if blacklist_weight_modules:
         decay, no_decay = split_decay_groups(model, list(blacklist_weight_modules))
         params = dict(model.named_parameters())
         logger.info("Weight decay will not be applied to: %s", no_decay)
         groups = [{"params": [params[n] for n in decay], "weight_decay": weight_decay},
                   {"params": [params[n] for n in no_decay], "weight_decay": 0.0}]
-        optimizer = opt_cls(groups, lr=max_lr, betas=betas, eps=eps)
+        optimizer = opt_cls(groups, lr=max_lr, betas=betas, eps=eps, **extra)
     else:
-        optimizer = opt_cls(model.parameters(), lr=max_lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        optimizer = opt_cls(model.parameters(), lr=max_lr, betas=betas, eps=eps, weight_decay=weight_decay, **extra)
     n_warm = int(warmup_steps_ratio * steps)
     warm = _warmup(optimizer, n_warm, scheduler_names[0])
     main = _main(optimizer, int(steps - warmup_steps_ratio * steps), scheduler_names[1])

@@ -15,6 +15,11 @@ from ..env_definitions import ACTION_DIM, OBS_DIM
 from .transformer_encoder import TransformerEncoder
 
 
+def _one_hot(boards: torch.Tensor, classes: int, dtype) -> torch.Tensor:
+    """[B, 16] integer boards -> [B, 16, classes] one-hot without the host-side range check of F.one_hot."""
+    return (boards.unsqueeze(-1) == torch.arange(classes, device=boards.device, dtype=boards.dtype)).to(dtype)
+
+
 def _head(d_in: int, hidden: int, d_out: int) -> nn.Sequential:
     return nn.Sequential(nn.Linear(d_in, hidden), nn.ReLU(), nn.Linear(hidden, hidden), nn.ReLU(),
                          nn.Linear(hidden, d_out, bias=False))
@@ -37,14 +42,14 @@ class _ActorCritic(nn.Module):
     def get_action(self, observations, action_mask=None):
         """Sample -> (actions, log_probs, values)."""
         logits, values = self.forward(observations, action_mask)
-        dist = Categorical(logits=logits)
+        dist = Categorical(logits=logits, validate_args=False)  # no host sync: capturable in a hipGraph
         actions = dist.sample()
         return actions, dist.log_prob(actions), values
 
     def evaluate_actions(self, observations, actions, action_mask=None):
         """-> (log_probs of ``actions``, values, entropy)."""
         logits, values = self.forward(observations, action_mask)
-        dist = Categorical(logits=logits)
+        dist = Categorical(logits=logits, validate_args=False)  # no host sync: capturable in a hipGraph
         return dist.log_prob(actions), values, dist.entropy()
 
 
@@ -65,7 +70,13 @@ class PPOAgent(_ActorCritic):
 
     def embed(self, observations: torch.Tensor) -> torch.Tensor:
         if observations.dtype in (torch.uint8, torch.int16, torch.int32, torch.int64):  # packed boards [B, 16]
-            return F.embedding(observations.long(), self.input_embedding.weight.t())
+            w = self.input_embedding.weight
+            if torch.is_grad_enabled() and w.requires_grad:
+                # training: expand to one-hot on the fly and use the Linear, so the weight gradient is a small
+                # dense GEMM (the sort-based embedding backward sizes its launches on the host and cannot be
+                # replayed from a hipGraph)
+                return self.input_embedding(_one_hot(observations, self.observation_dim, w.dtype))
+            return F.embedding(observations.long(), w.t())
         return self.input_embedding(observations)
 
     def features(self, observations):
@@ -88,7 +99,10 @@ class MLPAgent(_ActorCritic):
 
     def features(self, observations):
         if observations.dtype in (torch.uint8, torch.int16, torch.int32, torch.int64):
-            # one-hot @ W^T == sum over cells of the selected weight columns
+            if torch.is_grad_enabled() and self.trunk_in.weight.requires_grad:
+                h = self.trunk_in(_one_hot(observations, self.observation_dim, self.trunk_in.weight.dtype).flatten(1))
+                return F.relu(self.trunk_hidden(F.relu(h)))
+            # inference: one-hot @ W^T == sum over cells of the selected weight columns
             cols = observations.long() + torch.arange(self.board_cells, device=observations.device) * self.observation_dim
             h = F.embedding(cols, self.trunk_in.weight.t()).sum(dim=1) + self.trunk_in.bias
         else:

@@ -67,6 +67,59 @@ def _tail(seq, k: int):
     return items[-k:] if k > 0 else []
 
 
+class _GraphedFwdBwd:
+    """One minibatch of ``_compute_ppo_loss`` + (scaled) backward captured in a hipGraph.
+
+    Inputs are copied into static buffers, the graph is replayed, gradients land in static ``.grad`` tensors
+    (or in the flat all-reduce bucket when it exists); clipping, the optimizer and the LR schedule stay eager.
+    Dropout draws fresh masks on every replay (graph-safe philox offsets)."""
+
+    def __init__(self, trainer: "PPOTrainer", M: int, sample: dict):
+        self.tr, self.M = trainer, M
+        dev = trainer.device
+        self.static = {k: torch.empty_like(v) for k, v in sample.items()}
+        for k, v in sample.items():
+            self.static[k].copy_(v)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):  # warm-up off the capture stream (allocator, autocast caches, lazy inits)
+                self._zero()
+                self._fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        if trainer._flat_grad is None:
+            trainer.optimizer.zero_grad(set_to_none=True)  # backward inside the capture creates static grads
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            if trainer._flat_grad is not None:
+                trainer._flat_grad.zero_()
+            self.out = self._fwd_bwd()
+
+    def _zero(self):
+        self.tr._zero_grad()
+
+    def _fwd_bwd(self):
+        tr, st = self.tr, self.static
+        args = (st["obs"], st["actions"], st["masks"], st["old_lp"], st["adv"], st["ret"])
+        if tr.use_amp:
+            with autocast(device_type="cuda", dtype=tr.amp_dtype):
+                loss, pl, vl, el, new_lp = tr._compute_ppo_loss(*args)
+            tr.scaler.scale(loss).backward()
+        else:
+            loss, pl, vl, el, new_lp = tr._compute_ppo_loss(*args)
+            loss.backward()
+        with torch.no_grad():
+            stats = torch.stack([pl.mean(), vl.mean(), el.mean(), loss.detach()]).double()
+            kl = (st["old_lp"] - new_lp).mean().double()
+        return stats, kl
+
+    def run(self, batch: dict):
+        for k, v in batch.items():
+            self.static[k].copy_(v)
+        self.graph.replay()
+        return self.out
+
+
 class PPOTrainer:
     def __init__(self, agent, batch_runner: BatchRunner, rollout_buffer: RolloutBuffer, optimizer_param_dict: Dict,
                  max_steps: int, gamma: float = 0.99, lambda_gae: float = 0.95, clip_epsilon: float = 0.2,
@@ -74,7 +127,7 @@ class PPOTrainer:
                  target_kl: float = 0.01, use_action_mask: bool = False, device: torch.device = torch.device("cpu"),
                  mixed_precision: Optional[Literal["float16", "bfloat16"]] = "bfloat16",
                  max_samples_per_epoch: int = None, shuffle_on_reset: bool = False, rollout_amp: bool = False,
-                 log_dir: str = "logs"):
+                 log_dir: str = "logs", use_hip_graph: bool = True):
         self.agent = agent.to(device)
         self.batch_runner = batch_runner
         self.rollout_buffer = rollout_buffer
@@ -109,6 +162,11 @@ class PPOTrainer:
             self._bind_flat_grads()
             self._broadcast_parameters()
 
+        # forward + loss + backward of one minibatch replayed as a hipGraph (the update at minibatch 2048 is
+        # launch-bound: ~300 small kernels); built lazily per minibatch size, see _GraphedFwdBwd
+        self.use_hip_graph = bool(use_hip_graph) and self.device.type == "cuda"
+        self._graphs = {}
+
         self.writer = _make_writer(log_dir) if self.rank == 0 else _NullWriter()
         self.total_timesteps = 0
         self.total_epochs = 0
@@ -140,7 +198,8 @@ class PPOTrainer:
         if self._flat_grad is not None:
             self._flat_grad.zero_()
         else:
-            self.optimizer.zero_grad()
+            # once a hipGraph owns the .grad tensors they must stay allocated (the replay writes into them)
+            self.optimizer.zero_grad(set_to_none=not self._graphs)
 
     def _allreduce_grads(self):
         if self.world > 1:
@@ -256,28 +315,40 @@ class PPOTrainer:
                 if done_batches >= n_per_epoch:
                     break
                 obs, actions, masks, old_lp, adv, ret = self._unpack_batch(batch)
-                if self.use_amp:
-                    with autocast(device_type="cuda", dtype=self.amp_dtype):
-                        loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
+                graphed = None
+                if self.use_hip_graph and obs.shape[0] == batch_size:
+                    sample = dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret)
+                    gkey = (batch_size, obs.dtype, tuple(obs.shape[1:]))
+                    if gkey not in self._graphs:
+                        self._graphs[gkey] = _GraphedFwdBwd(self, batch_size, sample)
+                    graphed = self._graphs[gkey]
+                    stats, kl = graphed.run(sample)
                 else:
-                    loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
-                self._zero_grad()
+                    if self.use_amp:
+                        with autocast(device_type="cuda", dtype=self.amp_dtype):
+                            loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
+                    else:
+                        loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
+                    self._zero_grad()
+                    if self.use_amp:
+                        self.scaler.scale(loss).backward()
+                    else:
+                        loss.backward()
+                    with torch.no_grad():
+                        stats = torch.stack([pl.mean(), vl.mean(), el.mean(), loss.detach()]).double()
+                        kl = (old_lp - new_lp).mean().double()
+                self._allreduce_grads()
                 if self.use_amp:
-                    self.scaler.scale(loss).backward()
-                    self._allreduce_grads()
                     self.scaler.unscale_(self.optimizer)
                     torch.nn.utils.clip_grad_norm_(self.agent.parameters(), self.max_grad_norm)
                     self.scaler.step(self.optimizer)
                     self.scaler.update()
                 else:
-                    loss.backward()
-                    self._allreduce_grads()
                     torch.nn.utils.clip_grad_norm_(self.agent.parameters(), self.max_grad_norm)
                     self.optimizer.step()
                 self.lr_scheduler.step()
-                with torch.no_grad():
-                    sums += torch.stack([pl.mean(), vl.mean(), el.mean(), loss.detach()]).double()
-                    kl_sum += (old_lp - new_lp).mean().double()
+                sums += stats
+                kl_sum += kl
                 n_updates += 1
                 done_batches += 1
                 self.total_update_steps += 1
@@ -345,8 +416,11 @@ class PPOTrainer:
                 self.scaler.load_state_dict(ckpt["scaler_state_dict"])
             except Exception as e:
                 logger.warning("Failed to load GradScaler state: %s", e)
+        self._graphs.clear()  # captured graphs point at the old gradient buffers
         if self._flat_grad is not None:
             self._bind_flat_grads()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         logger.info("Checkpoint loaded: %d timesteps, %d epochs, %d update steps", self.total_timesteps,
                     self.total_epochs, self.total_update_steps)
         if self.episode_rewards:

@@ -77,8 +77,16 @@ def step_kernel_roofline(dev, boards_per_launch: int, launches: int = 20):
     torch.cuda.synchronize()
     us = start.elapsed_time(end) * 1e3 / launches
     gbs = STEP_BYTES * B / (us * 1e-6) / 1e9
+    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE x2
+    # gfx950 correction), scaled to this launch size; null if that profile is not in the tree
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "step_kernel_pmc_latest.json")))
+        traffic = round(pmc["hbm_bytes_per_env_step"] * B)
+    except Exception:
+        pass
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_step (g2048_step)",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_step (g2048_step)",
             "boards_per_launch": B, "launch_us": round(us, 2), "algorithmic_bytes_per_env_step": STEP_BYTES,
             "live_fraction": round(live, 3)}
 
@@ -161,10 +169,20 @@ def main():
                          rollout_amp=True, log_dir=os.path.join("/tmp", f"g2048_bench_logs_{rank}"), **TRAINER_CFG)
     global_boards = args.boards * world
 
-    def one_step():
+    phase = {"collect_s": 0.0, "update_s": 0.0}
+
+    def one_step(record=False):
+        t_a = time.perf_counter()
         trainer.collect_rollouts(global_boards, 1)
         n = trainer.last_rollout_stats["timesteps"]
+        if record:
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
         trainer.update_policy(batch_size=args.train_batch, n_epochs=args.epochs)
+        if record:
+            torch.cuda.synchronize()
+            phase["collect_s"] += t_b - t_a
+            phase["update_s"] += time.perf_counter() - t_b
         return n
 
     def sync():
@@ -179,7 +197,7 @@ def main():
     t0 = time.perf_counter()
     env_steps = 0
     for _ in range(args.steps):
-        env_steps += one_step()
+        env_steps += one_step(record=True)
     sync()
     elapsed = time.perf_counter() - t0
     timed.on = False
@@ -200,6 +218,8 @@ def main():
                    "update_epochs": args.epochs, "max_samples_per_epoch": TRAINER_CFG["max_samples_per_epoch"],
                    "rng_mode": "partitionable", "parallelism": f"env-shard x{world} + 1 grad all-reduce/minibatch"},
         "env_steps_per_ppo_iteration": int(env_steps / max(args.steps, 1)),
+        "phase_seconds_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in phase.items()},
+        "update_minibatches_per_step": trainer.total_update_steps // max(args.steps + args.warmup, 1),
     }
     if rank == 0:
         us = timed.mean_us()
