@@ -52,14 +52,22 @@ G_DEV u32 rotl(u32 x, int r) {
 #endif
 }
 
-// v_perm_b32: result byte i = byte (sel >> 8i & 7) of the 8-byte pool {lo: 0..3, hi: 4..7}
+// v_perm_b32: result byte i is chosen by selector byte i from the 8-byte pool {lo: 0..3, hi: 4..7};
+// selector 8/9/10/11 = sign of pool byte 1/3/5/7 replicated, 12 = 0x00, >= 13 = 0xFF.
 G_DEV u32 perm(u32 hi, u32 lo, u32 sel) {
 #if G2048_ON_DEVICE
     return __builtin_amdgcn_perm(hi, lo, sel);
 #else
     uint64_t pool = ((uint64_t)hi << 32) | lo;
     u32 out = 0;
-    for (int i = 0; i < 4; ++i) out |= (u32)((pool >> (8 * ((sel >> (8 * i)) & 7))) & 0xFF) << (8 * i);
+    for (int i = 0; i < 4; ++i) {
+        const u32 s = (sel >> (8 * i)) & 0xFF;
+        u32 v;
+        if (s < 8) v = (u32)((pool >> (8 * s)) & 0xFF);
+        else if (s < 12) v = ((pool >> (8 * (2 * (s - 8) + 1) + 7)) & 1) ? 0xFFu : 0u;
+        else v = s == 12 ? 0u : 0xFFu;
+        out |= v << (8 * i);
+    }
     return out;
 #endif
 }
@@ -163,25 +171,47 @@ G_DEV void bits_vec4(u32 k0, u32 k1, u32 out[4]) {
 // ------------------------------------------------------------------------------------------------
 // board arithmetic
 // ------------------------------------------------------------------------------------------------
-// Slide one row toward byte 0 with 2048 merges; adds the merge score (sum of new tile values).
-G_DEV u32 slide_row(u32 x, u32 &score) {
-    // squeeze out empty cells, highest gap first so the part above is already packed
-    if ((x & 0x00FF0000u) == 0) x = (x & 0x0000FFFFu) | ((x >> 8) & 0x00FF0000u);
-    if ((x & 0x0000FF00u) == 0) x = (x & 0x000000FFu) | ((x >> 8) & 0x00FFFF00u);
-    if ((x & 0x000000FFu) == 0) x = x >> 8;
-    const u32 a = x & 0xFF, b = (x >> 8) & 0xFF, c = (x >> 16) & 0xFF, d = x >> 24;
-    // packed row: a tile equals its right neighbour and that neighbour is a tile
-    const bool e01 = (a == b) & (b != 0);
-    const bool e12 = (b == c) & (c != 0) & !e01;
-    const bool e23 = (c == d) & (d != 0) & !e12;
-    const u32 a1 = a + 1, c1 = c + 1;
-    u32 r = x;
-    r = e23 ? ((x & 0x0000FFFFu) | (c1 << 16)) : r;                       // [a, b, c+1, 0]
-    r = e12 ? (a | ((b + 1) << 8) | (d << 16)) : r;                       // [a, b+1, d, 0]
-    r = e01 ? (a1 | ((x >> 8) & 0x00FFFF00u)) : r;                        // [a+1, c, d, 0]
-    r = (e01 & e23) ? (a1 | (c1 << 8)) : r;                               // [a+1, c+1, 0, 0]
-    score += (e01 ? (2u << a) : 0u) + (e12 ? (2u << b) : 0u) + (e23 ? (2u << c) : 0u);
-    return r;
+// 0xFF in every byte of x that holds a tile, 0x00 in empty bytes (cell values <= 0x80).
+// x + 0x7F.. puts "non-zero" into bit 7 of each byte; v_perm's sign-replicating selectors widen bit 7 of
+// pool bytes 1/3/5/7 to full bytes, so one shift + one perm finish the job.
+G_DEV u32 nz_mask(u32 x) {
+    const u32 y = x + 0x7F7F7F7Fu;
+    return perm(y << 8, y, 0x090B080Au);
+}
+
+// (m & x) | (~m & y)  -> v_bfi_b32
+G_DEV u32 bfi(u32 m, u32 x, u32 y) { return (m & x) | (~m & y); }
+
+// Slide the four columns of the board toward row register a (2048 merge rules), all four columns at once:
+// byte lane c of (a, b, c, d) is column c from the wall outward.  Returns the merge score of the four lines.
+G_DEV u32 slide_lines(u32 &a, u32 &b, u32 &c, u32 &d) {
+    // squeeze out empty cells, outermost gap first (afterwards every line is packed against a)
+    u32 m = nz_mask(c);
+    c = bfi(m, c, d);  d &= m;
+    m = nz_mask(b);
+    b = bfi(m, b, c);  c = bfi(m, c, d);  d &= m;
+    m = nz_mask(a);
+    a = bfi(m, a, b);  b = bfi(m, b, c);  c = bfi(m, c, d);  d &= m;
+    // a tile merges with its outer neighbour when equal; a merged tile does not merge again (left-to-right scan)
+    const u32 e01 = ~nz_mask(a ^ b) & nz_mask(b);
+    const u32 e12 = ~nz_mask(b ^ c) & nz_mask(c) & ~e01;
+    const u32 e23 = ~nz_mask(c ^ d) & nz_mask(d) & ~e12;
+    const u32 both = e01 & e23, ones = 0x01010101u;
+    const u32 na = a + (e01 & ones);                                   // [a+1 | a]
+    const u32 nb = bfi(e01, c, b) + ((e12 | both) & ones);             // [c(+1) | b+1 | b]
+    const u32 nc = (bfi(e01 | e12, d, c) + (e23 & ~e01 & ones)) & ~both;  // [0 | d | c+1 | c]
+    const u32 nd = d & ~(e01 | e12 | e23);
+    // score: every merge creates one tile 2^e, e = the new exponent (>= 2)
+    const u32 first = (na & e01) | (nb & e12) | (nc & e23 & ~e01);   // one merge per line ...
+    const u32 second = nb & both;                                     // ... plus the (c,d) merge when both fire
+    const u32 vf = (e01 | e12 | e23) & ones, vs = both & ones;
+    u32 score = 0;
+    for (int i = 0; i < 4; ++i) {
+        score += ((vf >> (8 * i)) & 0xFFu) << ((first >> (8 * i)) & 0xFFu);
+        score += ((vs >> (8 * i)) & 0xFFu) << ((second >> (8 * i)) & 0xFFu);
+    }
+    a = na; b = nb; c = nc; d = nd;
+    return score;
 }
 
 // 4x4 byte transpose of the four row dwords (8 v_perm_b32)
@@ -197,22 +227,22 @@ G_DEV void transpose(Board &bd) {
 }
 
 // Slide/merge the whole board in direction a (0 left, 1 up, 2 right, 3 down); returns merge score.
-// Divergence-free: the direction only selects byte permutations around the same four row slides.
+// Divergence-free: horizontal moves are the vertical move of the transposed board, right/down are the
+// left/up move with the line order reversed -- the direction only selects permutations around one
+// column-parallel slide.
 G_DEV u32 board_move(Board &bd, u32 a) {
-    const bool vertical = (a & 1u) != 0;
-    const u32 rev = (a & 2u) ? 0x00010203u : 0x03020100u;  // right/down: mirror each line
+    const bool horizontal = (a & 1u) == 0, reverse = (a & 2u) != 0;
     Board t = bd;
     transpose(t);
-    for (int i = 0; i < 4; ++i) t.r[i] = vertical ? t.r[i] : bd.r[i];
-    u32 score = 0;
-    for (int i = 0; i < 4; ++i) {
-        u32 x = perm(t.r[i], t.r[i], rev);
-        x = slide_row(x, score);
-        t.r[i] = perm(x, x, rev);
-    }
+    for (int i = 0; i < 4; ++i) t.r[i] = horizontal ? t.r[i] : bd.r[i];
+    u32 x0 = reverse ? t.r[3] : t.r[0], x1 = reverse ? t.r[2] : t.r[1];
+    u32 x2 = reverse ? t.r[1] : t.r[2], x3 = reverse ? t.r[0] : t.r[3];
+    const u32 score = slide_lines(x0, x1, x2, x3);
+    t.r[0] = reverse ? x3 : x0; t.r[1] = reverse ? x2 : x1;
+    t.r[2] = reverse ? x1 : x2; t.r[3] = reverse ? x0 : x3;
     Board u = t;
     transpose(u);
-    for (int i = 0; i < 4; ++i) bd.r[i] = vertical ? u.r[i] : t.r[i];
+    for (int i = 0; i < 4; ++i) bd.r[i] = horizontal ? u.r[i] : t.r[i];
     return score;
 }
 

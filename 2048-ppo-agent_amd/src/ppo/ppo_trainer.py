@@ -102,7 +102,9 @@ class _GraphedFwdBwd:
         tr, st = self.tr, self.static
         args = (st["obs"], st["actions"], st["masks"], st["old_lp"], st["adv"], st["ret"])
         if tr.use_amp:
-            with autocast(device_type="cuda", dtype=tr.amp_dtype):
+            # autocast's weight-cast cache must be off inside a captured region (PyTorch CUDA-graphs + AMP rule):
+            # with it on, the replayed graph produced non-finite bias gradients
+            with autocast(device_type="cuda", dtype=tr.amp_dtype, cache_enabled=False):
                 loss, pl, vl, el, new_lp = tr._compute_ppo_loss(*args)
             tr.scaler.scale(loss).backward()
         else:
@@ -127,7 +129,7 @@ class PPOTrainer:
                  target_kl: float = 0.01, use_action_mask: bool = False, device: torch.device = torch.device("cpu"),
                  mixed_precision: Optional[Literal["float16", "bfloat16"]] = "bfloat16",
                  max_samples_per_epoch: int = None, shuffle_on_reset: bool = False, rollout_amp: bool = False,
-                 log_dir: str = "logs", use_hip_graph: bool = True):
+                 log_dir: str = "logs", use_hip_graph: bool = False):
         self.agent = agent.to(device)
         self.batch_runner = batch_runner
         self.rollout_buffer = rollout_buffer
@@ -162,10 +164,15 @@ class PPOTrainer:
             self._bind_flat_grads()
             self._broadcast_parameters()
 
-        # forward + loss + backward of one minibatch replayed as a hipGraph (the update at minibatch 2048 is
-        # launch-bound: ~300 small kernels); built lazily per minibatch size, see _GraphedFwdBwd
+        # OPT-IN: forward + loss + backward of one minibatch replayed as a hipGraph (-25 % per minibatch of 2048,
+        # ~300 small kernels).  Off by default: on ROCm 7.2 / torch 2.10 the replayed graph yields non-finite
+        # bias gradients under bf16 autocast (fp32 is fine; tools/debug_nan.py reproduces it), so it is only
+        # safe with mixed_precision=None.  Built lazily per minibatch size, see _GraphedFwdBwd.
         self.use_hip_graph = bool(use_hip_graph) and self.device.type == "cuda"
         self._graphs = {}
+        if self.use_hip_graph and self._flat_grad is None:
+            # static gradient memory for the graph: backward accumulates in place into views of one bucket
+            self._bind_flat_grads()
 
         self.writer = _make_writer(log_dir) if self.rank == 0 else _NullWriter()
         self.total_timesteps = 0

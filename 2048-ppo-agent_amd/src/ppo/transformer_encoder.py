@@ -69,16 +69,28 @@ class TransformerEncoder(nn.Module):
                                        norm_first=True, batch_first=True),
             num_layers=num_layers, enable_nested_tensor=False)
 
-    def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor) -> torch.Tensor:
+    def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor, cls_only: bool = False) -> torch.Tensor:
+        """One pre-norm encoder layer.  With ``cls_only`` only the CLS row of the output is produced (keys and
+        values still come from every token): that is all the "cls" reduction reads from the LAST layer, and it
+        skips 16/17 of that layer's query/out-projection/FFN work."""
         B, S, D = x.shape
         H = self.nhead
         p = self.dropout if self.training else 0.0
         attn = layer.self_attn
         h = F.layer_norm(x, (D,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-        qkv = F.linear(h, attn.in_proj_weight, attn.in_proj_bias).view(B, S, 3, H, D // H)
-        q, k, v = qkv.unbind(dim=2)
+        if cls_only:
+            w, b = attn.in_proj_weight, attn.in_proj_bias
+            q = F.linear(h[:, :1], w[:D], b[:D]).view(B, 1, H, D // H)
+            kv = F.linear(h, w[D:], b[D:]).view(B, S, 2, H, D // H)
+            k, v = kv.unbind(dim=2)
+            x = x[:, :1]
+            S_out = 1
+        else:
+            qkv = F.linear(h, attn.in_proj_weight, attn.in_proj_bias).view(B, S, 3, H, D // H)
+            q, k, v = qkv.unbind(dim=2)
+            S_out = S
         a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), dropout_p=p)
-        a = F.linear(a.transpose(1, 2).reshape(B, S, D), attn.out_proj.weight, attn.out_proj.bias)
+        a = F.linear(a.transpose(1, 2).reshape(B, S_out, D), attn.out_proj.weight, attn.out_proj.bias)
         x = x + F.dropout(a, p, self.training)
         h = F.layer_norm(x, (D,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
         f = F.dropout(F.relu(F.linear(h, layer.linear1.weight, layer.linear1.bias)), p, self.training)
@@ -91,8 +103,9 @@ class TransformerEncoder(nn.Module):
             raise ValueError(f"reduction must be 'mean' or 'cls', got {reduction}")
         x = self.positional_encoding.forward_flat(src)
         x = torch.cat([self.cls_token.to(x.dtype).expand(x.shape[0], -1, -1), x], dim=1)
-        for layer in self.encoder.layers:
-            x = self._layer(layer, x)
+        last = len(self.encoder.layers) - 1
+        for i, layer in enumerate(self.encoder.layers):
+            x = self._layer(layer, x, cls_only=(reduction == "cls" and i == last))
         if self.encoder.norm is not None:
             x = self.encoder.norm(x)
         return x[:, 0, :] if reduction == "cls" else x[:, 1:, :].mean(dim=1)

@@ -206,6 +206,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if not all(bool(torch.isfinite(p).all()) for p in agent.parameters()):
+        raise SystemExit("non-finite policy parameters after the timed region: the measurement is void")
     out = {
         "metric": "env-steps/sec at N parallel boards (full PPO loop: rollout with policy in the loop + GAE + update)",
         "value": round(env_steps / elapsed, 1), "unit": "env-steps/sec", "n_gpus": world, "steps": args.steps,
