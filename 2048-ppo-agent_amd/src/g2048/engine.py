@@ -78,6 +78,10 @@ class RolloutEngine:
         # costs milliseconds; the rollout itself is ~1 ms at 65 536 boards)
         self._ws = None
         self._ws_key = None
+        # multi-GPU: a callable int -> int returning the maximum over all ranks.  The reference's key chain
+        # advances by 1 + 2 T splits per rollout with T the longest episode of the WHOLE batch, so shards agree
+        # on it before advancing their (identical) host-side chains.
+        self.global_max = None
 
     # ------------------------------------------------------------------ buffers
     def _alloc_state(self, B):
@@ -115,8 +119,9 @@ class RolloutEngine:
     def _finish(self, bufs, state, init_boards, B, fill_frozen, key0, n_splits_done_fn):
         boards, masks, done, ep_len = state
         T = int(ep_len.max().item())
-        # the reference consumed exactly 1 + 2T splits (init + act/step per lock-step)
-        self.key, _ = nv.chain_keys(key0, 1 + 2 * T, self.rng_mode)
+        # the reference consumed exactly 1 + 2T splits (init + act/step per lock-step), T over the whole batch
+        T_chain = T if self.global_max is None else int(self.global_max(T))
+        self.key, _ = nv.chain_keys(key0, 1 + 2 * T_chain, self.rng_mode)
         return Trajectory(
             boards=bufs["boards"][:T], meta=bufs["meta"][:T], rewards=bufs["rewards"][:T],
             log_probs=None if bufs["logp"] is None else bufs["logp"][:T],

@@ -213,6 +213,11 @@ class PPOTrainer:
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self._group)
             self._flat_grad.div_(self.world)
 
+    def _global_max(self, value: int) -> int:
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._group)
+        return int(t.item())
+
     def _shard(self, batch_size: int):
         """This rank's slice of a global batch of ``batch_size`` envs."""
         if self.world == 1:
@@ -232,6 +237,8 @@ class PPOTrainer:
         self.batch_runner.act_fn = act
         local_b, env0, total = self._shard(batch_size)
         self.batch_runner.env0, self.batch_runner.total_envs = env0, total
+        if self.world > 1:
+            self.batch_runner._engine.global_max = self._global_max
         total_episodes = 0
         ep_rew, ep_len = [], []
         with torch.no_grad():
