@@ -149,11 +149,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    dev = torch.device("cuda", local_rank)
+    # G2048_BENCH_DRYRUN=1: rehearse the multi-rank control flow on ONE GPU (all ranks on cuda:0, gloo backend);
+    # the numbers of such a run mean nothing and the JSON line says so
+    dryrun = os.environ.get("G2048_BENCH_DRYRUN") == "1"
+    dev = torch.device("cuda", 0 if dryrun else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dryrun:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from src.actions import act_randomly
     from src.g2048 import native as nv
@@ -221,6 +227,7 @@ def main():
                    "rng_mode": "partitionable", "parallelism": f"env-shard x{world} + 1 grad all-reduce/minibatch"},
         "env_steps_per_ppo_iteration": int(env_steps / max(args.steps, 1)),
         "phase_seconds_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in phase.items()},
+        **({"DRYRUN": "all ranks shared one GPU over gloo: control-flow rehearsal, not a measurement"} if dryrun else {}),
         "update_minibatches_per_step": trainer.total_update_steps // max(args.steps + args.warmup, 1),
     }
     if rank == 0:
