@@ -41,6 +41,7 @@ SIGNATURES = {
     "g2048_gae_tb": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _dbl, _dbl, _vp],
     "g2048_gae_flat": [_vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp],
     "g2048_compact": [_vp] * 14 + [_i64, _i64, _vp],
+    "g2048_policy_encoder": [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp],
 }
 
 _lib = None
@@ -233,3 +234,12 @@ def compact(tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, ep_len, offsets,
         _dev(out_rewards, f32, N, "out_rewards"), _dev(out_logp, f32, N, "out_logp", optional=True),
         _dev(out_values, f32, N, "out_values", optional=True), _dev(out_terms, u8, N, "out_terms"), T, B,
         _stream()), "g2048_compact")
+
+
+def policy_encoder(boards, embed_table, cls_token, weights_bf16, params_f32, n_layers: int, features):
+    B = boards.numel() // 16
+    _check(load().g2048_policy_encoder(
+        _dev(boards, u8, 16 * B, "boards"), _dev(embed_table, f32, 16 * 31 * 256, "embed_table"),
+        _dev(cls_token, f32, 256, "cls_token"), _dev(weights_bf16, torch.bfloat16, n_layers * 786432, "weights_bf16"),
+        _dev(params_f32, f32, n_layers * 3328, "params_f32"), n_layers, _dev(features, f32, 256 * B, "features"), B,
+        _stream()), "g2048_policy_encoder")

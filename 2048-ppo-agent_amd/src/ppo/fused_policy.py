@@ -1,0 +1,77 @@
+"""Rollout-time policy forward through the fused MFMA encoder kernel (csrc/g2048_policy.hip).
+
+Usable when the agent is a PPOAgent of the reference's default shape (d_model 256, 8 heads, feed-forward 1024,
+"cls" reduction) on a HIP device and the rollout is asked to run in bf16.  The encoder (embedding -> 17-token
+Transformer -> CLS feature) is one kernel; the two 3-layer heads stay in PyTorch (bf16 autocast) on the [B, 256]
+features.  Same numerics class as torch.autocast(bf16): bf16 GEMM inputs, f32 accumulation/residual/statistics.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..g2048 import native as nv
+
+
+def supports(agent) -> bool:
+    from .ppo_agent import PPOAgent
+
+    if not isinstance(agent, PPOAgent) or agent.reduction != "cls":
+        return False
+    t = agent.transformer
+    p = next(agent.parameters())
+    return (t.d_model == 256 and t.nhead == 8 and t.dim_feedforward == 1024 and agent.observation_dim == 31
+            and t.encoder.norm is None and p.is_cuda
+            and all(abs(l.norm1.eps - 1e-5) < 1e-12 and abs(l.norm2.eps - 1e-5) < 1e-12 for l in t.encoder.layers))
+
+
+class FusedPolicy:
+    """Packs the agent's encoder weights for ``g2048_policy_encoder`` (re-pack with ``refresh()`` after an update)."""
+
+    def __init__(self, agent):
+        if not supports(agent):
+            raise ValueError("agent shape not supported by the fused encoder kernel")
+        self.agent = agent
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        a, t = self.agent, self.agent.transformer
+        emb = a.input_embedding.weight.t().float()  # [31, 256]
+        pe = t.positional_encoding.flat_table().float()  # [16, 256]
+        self.table = (pe[:, None, :] + emb[None, :, :]).contiguous()  # [16, 31, 256]
+        self.cls = t.cls_token.detach().float().reshape(256).contiguous()
+        w, p = [], []
+        # the kernel feeds accumulator tiles straight back in as MFMA operands; the hardware layout then walks the
+        # reduction index of every group of 16 in the order KPERM, so the matrices multiplied against such operands
+        # (in_proj, linear1, linear2) are stored with their input columns in that order
+        kperm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15], device=self.cls.device)
+
+        def permuted(m):
+            k = m.shape[1]
+            idx = (torch.arange(0, k, 16, device=m.device)[:, None] + kperm[None, :]).reshape(-1)
+            return m.detach()[:, idx]
+
+        for l in t.encoder.layers:
+            w += [permuted(l.self_attn.in_proj_weight), l.self_attn.out_proj.weight, permuted(l.linear1.weight),
+                  permuted(l.linear2.weight)]
+            p += [l.norm1.weight, l.norm1.bias, l.self_attn.in_proj_bias, l.self_attn.out_proj.bias, l.norm2.weight,
+                  l.norm2.bias, l.linear1.bias, l.linear2.bias]
+        self.weights = torch.cat([x.detach().reshape(-1).to(torch.bfloat16) for x in w]).contiguous()
+        self.params = torch.cat([x.detach().reshape(-1).float() for x in p]).contiguous()
+        self.n_layers = len(t.encoder.layers)
+
+    @torch.no_grad()
+    def features(self, boards: torch.Tensor) -> torch.Tensor:
+        boards = boards.contiguous()
+        out = torch.empty((boards.shape[0], 256), dtype=torch.float32, device=boards.device)
+        nv.policy_encoder(boards, self.table, self.cls, self.weights, self.params, self.n_layers, out)
+        return out
+
+    @torch.no_grad()
+    def __call__(self, boards: torch.Tensor):
+        """boards u8 [B, 16] -> (logits f32 [B, 4] (unmasked), values f32 [B])."""
+        feats = self.features(boards)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = self.agent.actor(feats)
+            values = self.agent.critic(feats)
+        return logits.float(), values.float().reshape(-1)

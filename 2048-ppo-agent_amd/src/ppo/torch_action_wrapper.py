@@ -22,14 +22,16 @@ class TorchActionFunction:
 
     Parameters mirror the reference: ``agent``, ``use_mask`` (apply the legal-action mask to the logits),
     ``sample_actions`` (categorical sample vs argmax), ``device`` (where the agent runs).  Extra:
-    ``amp_dtype`` runs the rollout forward under autocast (the reference rolls out in fp32), ``sync_every``
-    is how many lock-steps are enqueued between polls of the device-side live-env counter.
+    ``amp_dtype`` runs the rollout forward under autocast (the reference rolls out in fp32) -- for bfloat16 and a
+    PPOAgent of the reference's default shape the encoder then runs in the fused MFMA kernel unless
+    ``use_fused=False``; ``sync_every`` is how many lock-steps are enqueued between polls of the device-side
+    live-env counter.
     Side effect as in the reference: ``agent`` is moved to ``device`` and put in eval mode.
     """
 
     def __init__(self, agent, use_mask: bool = False, sample_actions: bool = True,
                  device: torch.device = torch.device("cpu"), amp_dtype: Optional[torch.dtype] = None,
-                 sync_every: int = 8, rng_mode=None):
+                 sync_every: int = 8, rng_mode=None, use_fused: Optional[bool] = None):
         self.agent = agent.to(device).eval()
         self.use_mask = use_mask
         self.sample_actions = sample_actions
@@ -37,6 +39,13 @@ class TorchActionFunction:
         self.amp_dtype = amp_dtype
         self.sync_every = sync_every
         self.rng_mode = rng_mode
+        # bf16 rollouts of a default-shape PPOAgent go through the fused MFMA encoder kernel (csrc/g2048_policy.hip)
+        self._fused = None
+        if amp_dtype == torch.bfloat16 and use_fused is not False:
+            from . import fused_policy
+
+            if fused_policy.supports(self.agent):
+                self._fused = fused_policy.FusedPolicy(self.agent)
         self._agent_params = dict(self.agent.named_parameters())
         self._agent_buffers = dict(self.agent.named_buffers())
         self._agent_state = {**self._agent_params, **self._agent_buffers}
@@ -46,6 +55,8 @@ class TorchActionFunction:
     def policy_fn(self, boards: torch.Tensor, masks: torch.Tensor):
         """boards u8 [B, 16], masks u8 [B] (unused here) -> (logits f32 [B, 4], values f32 [B])."""
         agent_dev = next(self.agent.parameters()).device
+        if self._fused is not None and boards.device == agent_dev:
+            return self._fused(boards)
         x = boards if boards.device == agent_dev else boards.to(agent_dev)
         if self.amp_dtype is not None and agent_dev.type == "cuda":
             with torch.autocast(device_type="cuda", dtype=self.amp_dtype):

@@ -131,6 +131,22 @@ int g2048_compact(const uint8_t *tr_boards, const uint8_t *tr_meta, const float 
                   uint8_t *out_boards, uint8_t *out_actions, uint8_t *out_masks, float *out_rewards,
                   float *out_logp, float *out_values, uint8_t *out_terms, int64_t T, int64_t B, void *stream);
 
+/* ---- policy network (inference) ------------------------------------------------------------------- */
+
+/* Fused bf16 forward of the reference's Transformer encoder at its default shape (d_model 256, 8 heads, ff 1024,
+ * 17 tokens, "cls" reduction): boards u8[B][16] -> features f32[B][256], i.e. PPOAgent's
+ * `self.transformer(self.input_embedding(obs), reduction="cls")` (src/ppo/ppo_agent.py:103-106,
+ * src/ppo/transformer_encoder.py:150-190) in eval mode under bf16 autocast numerics.
+ *   embed_table f32[16][31][256] = input_embedding.weight^T[e] + positional code of cell c
+ *   cls_token   f32[256]
+ *   weights_bf16, per layer: in_proj_weight[768][256] | out_proj.weight[256][256] | linear1.weight[1024][256] |
+ *                            linear2.weight[256][1024]                                     (bf16, 16-byte aligned)
+ *   params_f32,  per layer: norm1.weight[256] | norm1.bias[256] | in_proj_bias[768] | out_proj.bias[256] |
+ *                            norm2.weight[256] | norm2.bias[256] | linear1.bias[1024] | linear2.bias[256] */
+int g2048_policy_encoder(const uint8_t *boards, const float *embed_table, const float *cls_token,
+                         const void *weights_bf16, const float *params_f32, int n_layers, float *features,
+                         int64_t B, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

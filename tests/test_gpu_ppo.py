@@ -150,3 +150,47 @@ def test_kl_early_stop(dev, tmp_path, monkeypatch):
     tr.collect_rollouts(16, 1)
     tr.update_policy(batch_size=128, n_epochs=5)
     assert tr.total_epochs == 1  # mean(old - new) > target after the first epoch -> stop
+
+
+def test_fused_encoder_matches_autocast_forward(dev):
+    """g2048_policy_encoder (bf16 MFMA megakernel) vs the PyTorch encoder under bf16 autocast: same numerics class
+    (its distance to autocast is smaller than autocast's own distance to fp32), any batch size, any layer count."""
+    from src.ppo.fused_policy import FusedPolicy, supports
+
+    torch.manual_seed(0)
+    for layers in (1, 4):
+        agent = PPOAgent(hidden_dim=512, d_model=256, nhead=8, num_layers=layers, dim_feedforward=1024,
+                         reduction="cls").to(dev).eval()
+        with torch.no_grad():
+            for p in agent.parameters():
+                if p.dim() == 1:
+                    p.add_(torch.randn_like(p) * 0.05)  # non-trivial biases / LayerNorm affine
+        assert supports(agent)
+        fp = FusedPolicy(agent)
+        for B in (1, 7, 8, 100, 4097):
+            boards = torch.randint(0, 14, (B, 16), dtype=torch.uint8, device=dev)
+            with torch.no_grad():
+                ref32 = agent.features(boards)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    ref16 = agent.features(boards).float()
+                    l16, v16 = agent(boards)
+            got = fp.features(boards)
+            assert torch.isfinite(got).all()
+            err, base = (got - ref16).abs().mean().item(), (ref16 - ref32).abs().mean().item()
+            assert err < 1.5 * base + 1e-4, (layers, B, err, base)
+            assert (got - ref32).abs().max().item() < 0.05 * max(1.0, ref32.abs().max().item())
+            logits, values = fp(boards)
+            assert (logits - l16.float()).abs().max().item() < 0.05 and (values - v16.float().flatten()).abs().max().item() < 0.05
+    assert not supports(PPOAgent(d_model=128, nhead=8, num_layers=1, dim_feedforward=256).to(dev))
+    assert not supports(PPOAgent(reduction="mean").to(dev))
+
+
+def test_bf16_rollout_uses_fused_encoder_and_trains(dev, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    agent = PPOAgent(hidden_dim=512, d_model=256, nhead=8, num_layers=2, dim_feedforward=1024, reduction="cls")
+    tr = _trainer(dev, agent, rollout_amp=True)
+    tr.collect_rollouts(64, 1)
+    assert tr.batch_runner.act_fn._fused is not None
+    m = tr.update_policy(batch_size=256, n_epochs=1)
+    assert np.isfinite(m["total_loss"]) and abs(m["kl_divergence"]) < 0.05  # rollout and update policies agree
