@@ -28,7 +28,7 @@ def evaluate_max_tile(act_fn: Callable, num_episodes: int = 1000, seed: int = 42
         b = min(batch_size, num_episodes - done)
         runner = BatchRunner(init_seed=seed + i * batch_size, act_fn=act_fn, rng_mode=rng_mode, device=device)
         tr = runner.collect(b)
-        tiles.append(torch.pow(2.0, tr.final_boards.max(dim=1).values.double()).cpu().numpy())
+        tiles.append((1 << tr.final_boards.max(dim=1).values.cpu().numpy().astype(np.int64)))  # exact powers of two
         lengths.append(tr.ep_len.cpu().numpy())
         done += b
         i += 1

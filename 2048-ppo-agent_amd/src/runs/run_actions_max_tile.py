@@ -2,6 +2,7 @@
 import warnings
 from typing import Callable
 
+import numpy as np
 import torch
 
 from ..stats.running_stats_vec import RunningStatsVec
@@ -24,6 +25,6 @@ def run_actions_max_tile(init_seed: int, batch_size: int, num_envs: int, act_fn:
     for _ in range(num_envs // batch_size):
         tr = runner.collect(batch_size, fill_frozen=True)
         last_obs_boards = tr.boards[tr.T - 1]  # observation recorded at the last lock-step
-        max_tiles = torch.pow(2.0, last_obs_boards.max(dim=1).values.to(torch.float64))
-        stats.push(max_tiles.cpu().numpy().reshape(1, -1))
+        max_tiles = np.left_shift(1, last_obs_boards.max(dim=1).values.cpu().numpy().astype(np.int64))  # exact
+        stats.push(max_tiles.astype(np.float64).reshape(1, -1))
     return stats
