@@ -80,14 +80,48 @@ template <> __device__ __forceinline__ int swz<32>(int r) { return r & 15; }
 template <> __device__ __forceinline__ int swz<8>(int r) { return (r >> 1) & 7; }
 template <> __device__ __forceinline__ int swz<4>(int r) { return (r >> 2) & 3; }
 
-// Operand fragment (8 consecutive bf16 = chunk 2ks + h of the row) from a swizzled weight tile: one ds_read_b128.
+// Per-lane byte offsets of this lane's operand fragments inside a swizzled tile, computed once per kernel so that
+// every operand read is `ds_read_b128 base_vgpr + immediate` with no address arithmetic in the MFMA loops:
+// the row of M-tile m / output tile j only adds a multiple of 32 rows (a constant), and the XOR swizzle depends on
+// (row mod 32, chunk mod 16) only.
+struct LaneOff {
+    int a256[8];  // [32m + r][32 chunks]: chunk 2ks + h, ks mod 8   (+ 256 B for ks >= 8, + 16 KiB per M-tile)
+    int a64[4];   // [32j + r][8 chunks]:  chunk 2ks + h             (+ 4 KiB per j)
+    int a32[2];   // [32j + r][4 chunks]:  chunk 2ks + h             (+ 2 KiB per j)
+    // per-lane SOURCE byte offsets of the LDS-DMA instructions (see dma_tile)
+    unsigned s256[2], s64, s32;
+};
+__device__ __forceinline__ void lane_offsets(LaneOff &o, int r, int h, int w, int lane) {
+    for (int k = 0; k < 8; ++k) o.a256[k] = r * 512 + (((2 * k + h) ^ swz<32>(r)) * 16);
+    for (int k = 0; k < 4; ++k) o.a64[k] = r * 128 + (((2 * k + h) ^ swz<8>(r)) * 16);
+    for (int k = 0; k < 2; ++k) o.a32[k] = r * 64 + (((2 * k + h) ^ swz<4>(r)) * 16);
+    // DMA: wave-instruction t of wave w fills LDS chunks [(4t + w) * 64, +64); lane i supplies physical chunk
+    // P = (4t + w) * 64 + i = (row, p) and must fetch logical chunk q = p ^ swz(row) of that row.
+    for (int par = 0; par < 2; ++par) {  // [rows][32]: row = 8t + 2w + (i >> 5); the swizzle sees t only through t & 1
+        const int x = 2 * w + (lane >> 5), row15 = (8 * par + x) & 15;
+        o.s256[par] = (unsigned)(x * D * 2 + (((lane & 31) ^ row15) * 16));
+    }
+    {  // [256][8] slice of linear2.weight (row stride FF): row = 32t + 8w + (i >> 3)
+        const int x = 8 * w + (lane >> 3);
+        o.s64 = (unsigned)(x * FF * 2 + (((lane & 7) ^ swz<8>(x)) * 16));
+    }
+    {  // [256][4] slice of out_proj.weight (row stride D): row = 64t + 16w + (i >> 2)
+        const int x = 16 * w + (lane >> 2);
+        o.s32 = (unsigned)(x * D * 2 + (((lane & 3) ^ swz<4>(x)) * 16));
+    }
+}
+
+// Operand fragment (8 consecutive bf16 = chunk 2ks + h of row 32*mt + r) from a swizzled weight tile: one
+// ds_read_b128 at lane offset + constant.
 // When the OTHER operand comes out of an accumulator (frag_from_acc) its element j of lane-half h is
 // k = 16ks + 8(j>>2) + 4h + (j&3); tiles read against it are stored with the columns of every group of 16 in the
 // order KPERM = [0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15] (the host packs the weights that way, the kernel writes V^T
 // that way), so the same contiguous read delivers exactly those k.
 template <int CPR>
-__device__ __forceinline__ bf16x8 load_w(const char *tile, int row, int ks, int h) {
-    return *reinterpret_cast<const bf16x8 *>(tile + (row * CPR + ((2 * ks + h) ^ swz<CPR>(row))) * 16);
+__device__ __forceinline__ bf16x8 load_w(const char *tile, const LaneOff &o, int mt, int ks) {
+    if (CPR == 32) return *reinterpret_cast<const bf16x8 *>(tile + o.a256[ks & 7] + (ks >> 3) * 256 + mt * 32 * 512);
+    if (CPR == 8) return *reinterpret_cast<const bf16x8 *>(tile + o.a64[ks] + mt * 32 * 128);
+    return *reinterpret_cast<const bf16x8 *>(tile + o.a32[ks] + mt * 32 * 64);
 }
 // same from a padded kernel-written tile
 __device__ __forceinline__ bf16x8 load_p(const char *row, int ks, int h) {
@@ -114,9 +148,9 @@ __device__ __forceinline__ void frag_from_acc(const f32x16 &x, bf16x8 out[2]) {
 // chain: with one wave per SIMD nothing else hides the ~100-cycle LDS latency, and left alone the compiler emits
 // read -> wait -> MFMA per k-step.
 template <int CPR, int NK>
-__device__ __forceinline__ f32x16 gemm_tile(const char *tile, int row, const bf16x8 *b, f32x16 acc, int h) {
+__device__ __forceinline__ f32x16 gemm_tile(const char *tile, const LaneOff &o, int mt, const bf16x8 *b, f32x16 acc) {
     bf16x8 a[NK];
-    for (int ks = 0; ks < NK; ++ks) a[ks] = load_w<CPR>(tile, row, ks, h);
+    for (int ks = 0; ks < NK; ++ks) a[ks] = load_w<CPR>(tile, o, mt, ks);
     for (int ks = 0; ks < NK; ++ks) acc = mfma(a[ks], b[ks], acc);
     return acc;
 }
@@ -132,14 +166,18 @@ __device__ __forceinline__ void pipe_mfma() {
 
 // LDS-DMA of a [rows][CPR*8] bf16 tile (global row stride ld elements) into a swizzled LDS image.  Asynchronous:
 // complete for this wave after s_waitcnt vmcnt(0), for the other waves after the following barrier.
+// Source address = uniform tile base + uniform per-instruction step + per-lane offset from LaneOff.
 template <int CPR>
-__device__ __forceinline__ void dma_tile(char *dst, const __bf16 *src, int ld, int rows, int w, int lane) {
+__device__ __forceinline__ void dma_tile(char *dst, const __bf16 *src, int ld, int rows, const LaneOff &o, int w) {
     if (g_dbg & 1) return;  // timing-only switch (development): no weight stream, outputs are garbage
-    const int n_inst = rows * CPR / (64 * 4);  // wave-instructions per wave
+    const int n_inst = rows * CPR / (64 * 4);       // wave-instructions per wave
+    const int rows_per_inst = 4 * 64 / CPR;         // rows covered by one instruction of all four waves
+    const char *base = reinterpret_cast<const char *>(src);
     for (int t = 0; t < n_inst; ++t) {
-        const int base = (t * 4 + w) * 64, P = base + lane, r = P / CPR, p = P - r * CPR, q = p ^ swz<CPR>(r);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)r * ld + 8 * q),
-                                         (__attribute__((address_space(3))) void *)(dst + base * 16), 16, 0, 0);
+        const unsigned lane_off = CPR == 32 ? o.s256[t & 1] : (CPR == 8 ? o.s64 : o.s32);
+        const char *g = base + (size_t)t * rows_per_inst * ld * 2 + lane_off;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(dst + (t * 4 + w) * 1024), 16, 0, 0);
     }
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -188,6 +226,8 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const int64_t board0 = (int64_t)blockIdx.x * NBOARD;
     char *const wq = L.w, *const wk = L.w + TILE, *const wv = L.w + 2 * TILE;
+    LaneOff lo;
+    lane_offsets(lo, r, h, w, lane);
 
     // ---- this lane's token
     const int tok = 32 * w + r;                     // 0..127 inside the tile
@@ -210,12 +250,12 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
         const __bf16 *W = wblob + (size_t)layer * W_LAYER;
         const float *P = pblob + (size_t)layer * P_LAYER;
         auto dma_qkv = [&](int hd) {
-            dma_tile<32>(wq, W + WO_QKV + (size_t)(0 * D + HD * hd) * D, D, HD, w, lane);
-            dma_tile<32>(wk, W + WO_QKV + (size_t)(1 * D + HD * hd) * D, D, HD, w, lane);
-            dma_tile<32>(wv, W + WO_QKV + (size_t)(2 * D + HD * hd) * D, D, HD, w, lane);
+            dma_tile<32>(wq, W + WO_QKV + (size_t)(0 * D + HD * hd) * D, D, HD, lo, w);
+            dma_tile<32>(wk, W + WO_QKV + (size_t)(1 * D + HD * hd) * D, D, HD, lo, w);
+            dma_tile<32>(wv, W + WO_QKV + (size_t)(2 * D + HD * hd) * D, D, HD, lo, w);
         };
         auto wo_of = [&](int hd) -> char * { return L.w + (3 + (hd & 1)) * TILE; };  // double-buffered
-        auto dma_wo = [&](int hd) { dma_tile<4>(wo_of(hd), W + WO_O + HD * hd, D, D, w, lane); };
+        auto dma_wo = [&](int hd) { dma_tile<4>(wo_of(hd), W + WO_O + HD * hd, D, D, lo, w); };
 
         // ================= attention block =================
         __syncthreads();  // previous layer's feed-forward tiles (incl. the one aliasing `act`) are no longer read
@@ -236,9 +276,9 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
         for (int hd = 0; hd < NH; ++hd) {
             // Q^T, K^T, V^T [32 d][32 tok] for this wave's tokens
             const f32x16 zero = {0};
-            f32x16 qa = gemm_tile<32, 16>(wq, r, xn, zero, h);
-            f32x16 ka = gemm_tile<32, 16>(wk, r, xn, zero, h);
-            f32x16 va = gemm_tile<32, 16>(wv, r, xn, zero, h);
+            f32x16 qa = gemm_tile<32, 16>(wq, lo, 0, xn, zero);
+            f32x16 ka = gemm_tile<32, 16>(wk, lo, 0, xn, zero);
+            f32x16 va = gemm_tile<32, 16>(wv, lo, 0, xn, zero);
             pipe_mfma<48>();
             for (int g = 0; g < 4; ++g) {
                 bf16x4 qv, kv;
@@ -296,7 +336,7 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
             bf16x8 of[2];
             for (int ks = 0; ks < 2; ++ks) of[ks] = load_p(A.o + tok * ST32, ks, h);
             const char *wo = wo_of(hd);
-            for (int j = 0; j < 8; ++j) R[j] = gemm_tile<4, 2>(wo, 32 * j + r, of, R[j], h);
+            for (int j = 0; j < 8; ++j) R[j] = gemm_tile<4, 2>(wo, lo, j, of, R[j]);
             pipe_mfma<16>();
             dma_wait_all();
             __syncthreads();  // next head's tiles landed; Q/K/V^T/O of this head are free
@@ -306,8 +346,8 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
         auto w1_of = [&](int c) -> char * { return L.w + ((c & 1) ? 2 * TILE : 0); };
         auto w2_of = [&](int c) -> char * { return (c & 1) ? L.act.w2b : L.w + 4 * TILE; };
         auto dma_ffn = [&](int c) {
-            dma_tile<32>(w1_of(c), W + WO_1 + (size_t)(FFC * c) * D, D, FFC, w, lane);
-            dma_tile<8>(w2_of(c), W + WO_2 + FFC * c, FF, D, w, lane);
+            dma_tile<32>(w1_of(c), W + WO_1 + (size_t)(FFC * c) * D, D, FFC, lo, w);
+            dma_tile<8>(w2_of(c), W + WO_2 + FFC * c, FF, D, lo, w);
         };
         dma_ffn(0);
         stage_f32(L.bias, P + PO_BO, D, tid);
@@ -326,8 +366,8 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
             if (c + 1 < FF / FFC) dma_ffn(c + 1);  // lands while this stage computes
             const char *t1 = w1_of(c), *t2 = w2_of(c);
             const f32x16 zero = {0};
-            f32x16 h0 = gemm_tile<32, 16>(t1, r, xn, zero, h);
-            f32x16 h1 = gemm_tile<32, 16>(t1, 32 + r, xn, zero, h);
+            f32x16 h0 = gemm_tile<32, 16>(t1, lo, 0, xn, zero);
+            f32x16 h1 = gemm_tile<32, 16>(t1, lo, 1, xn, zero);
             pipe_mfma<32>();
             for (int i = 0; i < 16; ++i) {
                 h0[i] = fmaxf(h0[i] + L.bias[FFC * c + rowof(i, h)], 0.0f);
@@ -336,7 +376,7 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
             bf16x8 hf[4];
             frag_from_acc(h0, hf);
             frag_from_acc(h1, hf + 2);
-            for (int j = 0; j < 8; ++j) R[j] = gemm_tile<8, 4>(t2, 32 * j + r, hf, R[j], h);
+            for (int j = 0; j < 8; ++j) R[j] = gemm_tile<8, 4>(t2, lo, j, hf, R[j]);
             pipe_mfma<32>();
             dma_wait_all();
             __syncthreads();  // next stage landed; this stage's tiles are free
