@@ -134,7 +134,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--boards", type=int, default=65536, help="parallel boards per GPU")
+    ap.add_argument("--workload", default="transformer65536", choices=["transformer65536", "mlp4096"],
+                    help="transformer65536 = BASELINE.json configs[2] (the headline); mlp4096 = configs[1]: 4096 boards, "
+                         "MLP policy (flattened one-hot -> 512 -> 512 trunk + the reference's heads), full PPO loop")
+    ap.add_argument("--boards", type=int, default=None, help="parallel boards per GPU (default: per workload)")
     ap.add_argument("--train-batch", type=int, default=2048)
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--roofline-boards", type=int, default=1 << 24)
@@ -161,15 +164,17 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.boards is None:
+        args.boards = 65536 if args.workload == "transformer65536" else 4096
     from src.actions import act_randomly
     from src.g2048 import native as nv
-    from src.ppo import PPOAgent, PPOTrainer, RolloutBuffer
+    from src.ppo import MLPAgent, PPOAgent, PPOTrainer, RolloutBuffer
     from src.runs import BatchRunner
 
     timed = _TimedPolicyStep(nv)
     nv.policy_step = timed
     torch.manual_seed(0)
-    agent = PPOAgent(**MODEL_CFG)
+    agent = PPOAgent(**MODEL_CFG) if args.workload == "transformer65536" else MLPAgent(hidden_dim=512, trunk_dim=512)
     runner = BatchRunner(init_seed=0, rng_mode="partitionable", device=dev)
     trainer = PPOTrainer(agent, runner, RolloutBuffer(31, 16, 4), OPTIM_CFG, max_steps=500000, device=dev,
                          rollout_amp=True, log_dir=os.path.join("/tmp", f"g2048_bench_logs_{rank}"), **TRAINER_CFG)
@@ -220,8 +225,12 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 boards / bf16 policy",
         "data": "synthetic (self-play from seed 0, random-init policy weights)",
-        "config": {"workload": f"{args.boards} parallel boards per GPU, Transformer policy bf16 (3.96 M params), "
-                               f"full PPO iteration (BASELINE.json configs[2]; configs[3] when n_gpus=8)",
+        "config": {"workload": (f"{args.boards} parallel boards per GPU, Transformer policy bf16 (3.96 M params), "
+                                f"full PPO iteration (BASELINE.json configs[2]; configs[3] when n_gpus=8)"
+                                if args.workload == "transformer65536" else
+                                f"{args.boards} parallel boards per GPU, MLP policy bf16 "
+                                f"({sum(p.numel() for p in agent.parameters())} params), full PPO iteration "
+                                f"(BASELINE.json configs[1])"),
                    "boards_per_gpu": args.boards, "global_boards": global_boards, "train_batch": args.train_batch,
                    "update_epochs": args.epochs, "max_samples_per_epoch": TRAINER_CFG["max_samples_per_epoch"],
                    "rng_mode": "partitionable", "parallelism": f"env-shard x{world} + 1 grad all-reduce/minibatch"},
