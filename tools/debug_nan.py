@@ -12,7 +12,7 @@ tc = dict(bench.TRAINER_CFG)
 if '--noamp' in sys.argv: tc['mixed_precision'] = None
 tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31,16,4), bench.OPTIM_CFG, max_steps=500000, device=dev, rollout_amp=True, log_dir="/tmp/lg", use_hip_graph=("--graph" in sys.argv), **tc)
 import time
-for it in range(2):
+for it in range(3):
     tr.collect_rollouts(4096, 1)
     print("iter", it, "steps", tr.last_rollout_stats, flush=True)
     torch.cuda.synchronize(); t0=time.time(); m = tr.update_policy(batch_size=2048, n_epochs=2); torch.cuda.synchronize(); print(' ms/minibatch', (time.time()-t0)/max(m['n_updates'],1)*1e3)
