@@ -16,6 +16,7 @@ Also on the JSON line:
   roofline      the board-step kernel (g2048_step, 50 algorithmic bytes per env-step) at a saturating launch of
                 2^24 boards, timed with HIP events on its launch stream
   in_loop       the fused policy-step kernel as it ran inside the timed region (HIP events around every launch)
+  policy_encoder  the fused bf16 MFMA Transformer-encoder kernel used for rollout inference, against the dense MFMA peak
   env_only      fused random-policy rollout of the same 65 536 boards (no network): env-steps/sec
   cpu_baseline  the C oracle (OpenMP, all host cores) on a bounded sample of random-policy episodes (rank 0, N=1)
 """
@@ -89,6 +90,32 @@ def step_kernel_roofline(dev, boards_per_launch: int, launches: int = 20):
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_step (g2048_step)",
             "boards_per_launch": B, "launch_us": round(us, 2), "algorithmic_bytes_per_env_step": STEP_BYTES,
             "live_fraction": round(live, 3)}
+
+
+def policy_encoder_roofline(agent, dev, boards: int, launches: int = 5):
+    """The fused bf16 MFMA encoder kernel (g2048_policy_encoder) at the workload's batch, HIP events on its stream."""
+    from src.ppo import fused_policy
+
+    if not fused_policy.supports(agent):
+        return None
+    fp = fused_policy.FusedPolicy(agent)
+    x = torch.randint(0, 12, (boards, 16), dtype=torch.uint8, device=dev)
+    fp.features(x)
+    stream = torch.cuda.current_stream()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record(stream)
+    for _ in range(launches):
+        fp.features(x)
+    end.record(stream)
+    torch.cuda.synchronize()
+    ms = start.elapsed_time(end) / launches
+    layers = fp.n_layers
+    flop_per_board = layers * (17 * 2 * (256 * 768 + 256 * 256 + 2 * 256 * 1024) + 8 * 2 * 2 * 17 * 17 * 32)
+    tf = flop_per_board * boards / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+            "kernel": "k_encoder (g2048_policy_encoder)", "boards_per_launch": boards, "launch_ms": round(ms, 3),
+            "algorithmic_flop_per_board": flop_per_board, "dtype": "bf16 in / f32 accumulate"}
 
 
 class _TimedPolicyStep:
@@ -250,6 +277,9 @@ def main():
                               "algorithmic_bytes_per_env_step": POLICY_STEP_BYTES, "achieved_GBps": round(gbs, 1),
                               "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
         out["roofline"] = step_kernel_roofline(dev, args.roofline_boards)
+        enc = policy_encoder_roofline(agent, dev, args.boards)
+        if enc:
+            out["policy_encoder"] = enc
         if not args.no_extras:
             r = BatchRunner(init_seed=0, act_fn=act_randomly, rng_mode="partitionable", device=dev)
             r.collect(args.boards)  # warm
