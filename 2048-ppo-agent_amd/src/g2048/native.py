@@ -42,6 +42,10 @@ SIGNATURES = {
     "g2048_gae_flat": [_vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp],
     "g2048_compact": [_vp] * 14 + [_i64, _i64, _vp],
     "g2048_policy_encoder": [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp],
+    "g2048_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, C.c_float,
+                       C.c_float, C.c_uint64, _vp],
+    "g2048_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,
+                       C.c_float, C.c_float, C.c_uint64, _vp],
 }
 
 _lib = None
@@ -243,3 +247,20 @@ def policy_encoder(boards, embed_table, cls_token, weights_bf16, params_f32, n_l
         _dev(cls_token, f32, 256, "cls_token"), _dev(weights_bf16, torch.bfloat16, n_layers * 786432, "weights_bf16"),
         _dev(params_f32, f32, n_layers * 3328, "params_f32"), n_layers, _dev(features, f32, 256 * B, "features"), B,
         _stream()), "g2048_policy_encoder")
+
+
+def attn_fwd(q_ptr: int, k_ptr: int, v_ptr: int, o, lse, B: int, H: int, Sq: int, strides, scale: float, p_drop: float,
+             seed: int):
+    """q/k/v: raw device addresses inside bf16 tensors the caller keeps alive; strides = (q_sb, q_ss, k_sb, k_ss,
+    v_sb, v_ss) in elements."""
+    _check(load().g2048_attn_fwd(q_ptr, k_ptr, v_ptr, _dev(o, torch.bfloat16, B * Sq * H * 32, "o"),
+                                 _dev(lse, f32, B * H * Sq, "lse"), B, H, Sq, *[int(x) for x in strides], float(scale),
+                                 float(p_drop), int(seed), _stream()), "g2048_attn_fwd")
+
+
+def attn_bwd(q_ptr: int, k_ptr: int, v_ptr: int, dout, lse, dq_ptr: int, dk_ptr: int, dv_ptr: int, B: int, H: int,
+             Sq: int, strides, scale: float, p_drop: float, seed: int):
+    _check(load().g2048_attn_bwd(q_ptr, k_ptr, v_ptr, _dev(dout, torch.bfloat16, B * Sq * H * 32, "dout"),
+                                 _dev(lse, f32, B * H * Sq, "lse"), dq_ptr, dk_ptr, dv_ptr, B, H, Sq,
+                                 *[int(x) for x in strides], float(scale), float(p_drop), int(seed), _stream()),
+           "g2048_attn_bwd")

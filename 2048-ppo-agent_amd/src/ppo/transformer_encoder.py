@@ -51,6 +51,87 @@ class _LinearSplitK(torch.autograd.Function):
         return dx, dw.to(w_dtype), db
 
 
+def _seed() -> int:
+    return int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+
+
+class _AttnPacked(torch.autograd.Function):
+    """Self-attention over the packed in_proj output ``qkv`` [B, 17, 3*H*32] (bf16) through the HIP kernels
+    ``g2048_attn_fwd/bwd``; returns [B, 17, H*32] already in the layout out_proj reads.  The gradient is written
+    straight into a packed d(qkv) buffer.  Dropout acts on the attention probabilities, as nn.MultiheadAttention's."""
+
+    @staticmethod
+    def forward(ctx, qkv, nhead, p_drop):
+        from ..g2048 import native as nv
+
+        B, S, W = qkv.shape
+        hw = W // 3
+        qkv = qkv.contiguous()
+        o = torch.empty((B, S, hw), dtype=torch.bfloat16, device=qkv.device)
+        lse = torch.empty((B, nhead, S), dtype=torch.float32, device=qkv.device)
+        seed = _seed() if p_drop > 0 else 0
+        base = qkv.data_ptr()
+        strides = (S * W, W) * 3
+        nv.attn_fwd(base, base + 2 * hw, base + 4 * hw, o, lse, B, nhead, S, strides, (hw // nhead) ** -0.5, p_drop, seed)
+        ctx.save_for_backward(qkv, lse)
+        ctx.meta = (nhead, p_drop, seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        from ..g2048 import native as nv
+
+        qkv, lse = ctx.saved_tensors
+        nhead, p_drop, seed = ctx.meta
+        B, S, W = qkv.shape
+        hw = W // 3
+        dqkv = torch.empty_like(qkv)
+        base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+        nv.attn_bwd(base, base + 2 * hw, base + 4 * hw, do.contiguous(), lse, dbase, dbase + 2 * hw, dbase + 4 * hw, B,
+                    nhead, S, (S * W, W) * 3, (hw // nhead) ** -0.5, p_drop, seed)
+        return dqkv, None, None
+
+
+class _AttnCls(torch.autograd.Function):
+    """The CLS query of the last layer against all 17 keys: q [B, 1, H*32], kv [B, 17, 2*H*32] (bf16)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, nhead, p_drop):
+        from ..g2048 import native as nv
+
+        B, S, W = kv.shape
+        hw = W // 2
+        q, kv = q.contiguous(), kv.contiguous()
+        o = torch.empty((B, 1, hw), dtype=torch.bfloat16, device=kv.device)
+        lse = torch.empty((B, nhead, 1), dtype=torch.float32, device=kv.device)
+        seed = _seed() if p_drop > 0 else 0
+        kb = kv.data_ptr()
+        nv.attn_fwd(q.data_ptr(), kb, kb + 2 * hw, o, lse, B, nhead, 1, (hw, 0, S * W, W, S * W, W),
+                    (hw // nhead) ** -0.5, p_drop, seed)
+        ctx.save_for_backward(q, kv, lse)
+        ctx.meta = (nhead, p_drop, seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        from ..g2048 import native as nv
+
+        q, kv, lse = ctx.saved_tensors
+        nhead, p_drop, seed = ctx.meta
+        B, S, W = kv.shape
+        hw = W // 2
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        kb, db = kv.data_ptr(), dkv.data_ptr()
+        nv.attn_bwd(q.data_ptr(), kb, kb + 2 * hw, do.contiguous(), lse, dq.data_ptr(), db, db + 2 * hw, B, nhead, 1,
+                    (hw, 0, S * W, W, S * W, W), (hw // nhead) ** -0.5, p_drop, seed)
+        return dq, dkv, None, None
+
+
+def _fused_attention_ok(t: torch.Tensor, S: int, head_dim: int) -> bool:
+    return (t.is_cuda and t.dtype == torch.bfloat16 and S == 17 and head_dim == 32 and torch.is_grad_enabled()
+            and t.requires_grad)
+
+
 def _linear(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
     if (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad and torch.is_autocast_enabled()
             and torch.get_autocast_dtype("cuda") == torch.bfloat16):
@@ -124,17 +205,26 @@ class TransformerEncoder(nn.Module):
         h = F.layer_norm(x, (D,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
         if cls_only:
             w, b = attn.in_proj_weight, attn.in_proj_bias
-            q = _linear(h[:, :1], w[:D], b[:D]).view(B, 1, H, D // H)
-            kv = _linear(h, w[D:], b[D:]).view(B, S, 2, H, D // H)
-            k, v = kv.unbind(dim=2)
+            q = _linear(h[:, :1], w[:D], b[:D])
+            kv = _linear(h, w[D:], b[D:])
             x = x[:, :1]
             S_out = 1
+            if _fused_attention_ok(kv, S, D // H):
+                a = _AttnCls.apply(q, kv, H, p)
+            else:
+                k, v = kv.view(B, S, 2, H, D // H).unbind(dim=2)
+                a = F.scaled_dot_product_attention(q.view(B, 1, H, D // H).transpose(1, 2), k.transpose(1, 2),
+                                                   v.transpose(1, 2), dropout_p=p).transpose(1, 2).reshape(B, 1, D)
         else:
-            qkv = _linear(h, attn.in_proj_weight, attn.in_proj_bias).view(B, S, 3, H, D // H)
-            q, k, v = qkv.unbind(dim=2)
+            qkv = _linear(h, attn.in_proj_weight, attn.in_proj_bias)
             S_out = S
-        a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), dropout_p=p)
-        a = _linear(a.transpose(1, 2).reshape(B, S_out, D), attn.out_proj.weight, attn.out_proj.bias)
+            if _fused_attention_ok(qkv, S, D // H):
+                a = _AttnPacked.apply(qkv, H, p)
+            else:
+                q, k, v = qkv.view(B, S, 3, H, D // H).unbind(dim=2)
+                a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
+                                                   dropout_p=p).transpose(1, 2).reshape(B, S, D)
+        a = _linear(a, attn.out_proj.weight, attn.out_proj.bias)
         x = x + F.dropout(a, p, self.training)
         h = F.layer_norm(x, (D,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
         f = F.dropout(F.relu(_linear(h, layer.linear1.weight, layer.linear1.bias)), p, self.training)

@@ -147,6 +147,21 @@ int g2048_policy_encoder(const uint8_t *boards, const float *embed_table, const 
                          const void *weights_bf16, const float *params_f32, int n_layers, float *features,
                          int64_t B, void *stream);
 
+/* ---- policy network (update): attention for 17-token sequences ------------------------------------- */
+
+/* softmax(q k^T * scale) v with attention dropout, head_dim 32, Sk = 17 keys, Sq = 17 queries (or 1: the CLS row
+ * of the last layer); replaces F.scaled_dot_product_attention inside the encoder layers of the update
+ * (reference: nn.TransformerEncoderLayer built at src/ppo/transformer_encoder.py:138-148).
+ * q/k/v (and dq/dk/dv) are bf16 with element strides (batch, token) and heads contiguous inside a token, so they may
+ * point into the packed in_proj output [B][S][3][H][32] and its gradient; o/dout bf16 [B][Sq][H][32]; lse f32
+ * [B][H][Sq].  The dropout mask is a function of (seed, element index): pass the same seed to the backward. */
+int g2048_attn_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int H, int Sq,
+                   int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, float scale,
+                   float p_drop, uint64_t seed, void *stream);
+int g2048_attn_bwd(const void *q, const void *k, const void *v, const void *dout, const float *lse, void *dq, void *dk,
+                   void *dv, int64_t B, int H, int Sq, int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss,
+                   int64_t v_sb, int64_t v_ss, float scale, float p_drop, uint64_t seed, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

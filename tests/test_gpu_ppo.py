@@ -194,3 +194,45 @@ def test_bf16_rollout_uses_fused_encoder_and_trains(dev, tmp_path, monkeypatch):
     assert tr.batch_runner.act_fn._fused is not None
     m = tr.update_policy(batch_size=256, n_epochs=1)
     assert np.isfinite(m["total_loss"]) and abs(m["kl_divergence"]) < 0.05  # rollout and update policies agree
+
+
+def test_small_attention_kernels_match_sdpa(dev):
+    """g2048_attn_fwd/bwd (17 tokens, head_dim 32) vs torch SDPA: outputs and gradients as close to an fp32 reference as
+    SDPA's own bf16 path, packed and CLS-row variants, odd batch sizes; dropout keeps the expectation."""
+    import torch.nn.functional as F
+
+    from src.ppo.transformer_encoder import _AttnCls, _AttnPacked
+
+    H, hd, S = 8, 32, 17
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    torch.manual_seed(0)
+    for B in (1, 5, 683):
+        qkv = (torch.randn(B, S, 3 * H * hd, device=dev) * 1.5).to(torch.bfloat16).requires_grad_(True)
+        g = torch.randn(B, S, H * hd, device=dev).to(torch.bfloat16)
+        o = _AttnPacked.apply(qkv, H, 0.0)
+        o.backward(g)
+        x32 = qkv.detach().float().requires_grad_(True)
+        q, k, v = x32.view(B, S, 3, H, hd).unbind(2)
+        o32 = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).reshape(B, S, -1)
+        o32.backward(g.float())
+        assert rel(o, o32) < 4e-3 and rel(qkv.grad, x32.grad) < 4e-3
+        qc = torch.randn(B, 1, H * hd, device=dev).to(torch.bfloat16).requires_grad_(True)
+        kv = torch.randn(B, S, 2 * H * hd, device=dev).to(torch.bfloat16).requires_grad_(True)
+        gc = torch.randn(B, 1, H * hd, device=dev).to(torch.bfloat16)
+        oc = _AttnCls.apply(qc, kv, H, 0.0)
+        oc.backward(gc)
+        q32, kv32 = qc.detach().float().requires_grad_(True), kv.detach().float().requires_grad_(True)
+        k32, v32 = kv32.view(B, S, 2, H, hd).unbind(2)
+        oc32 = F.scaled_dot_product_attention(q32.view(B, 1, H, hd).transpose(1, 2), k32.transpose(1, 2),
+                                              v32.transpose(1, 2)).transpose(1, 2).reshape(B, 1, -1)
+        oc32.backward(gc.float())
+        assert rel(oc, oc32) < 4e-3 and rel(qc.grad, q32.grad) < 4e-3 and rel(kv.grad, kv32.grad) < 4e-3
+    qkv = torch.randn(2048, S, 3 * H * hd, device=dev).to(torch.bfloat16)
+    o0 = _AttnPacked.apply(qkv.clone().requires_grad_(True), H, 0.0).float()
+    acc = torch.zeros_like(o0)
+    for _ in range(16):
+        acc += _AttnPacked.apply(qkv.clone().requires_grad_(True), H, 0.1).float()
+    assert rel(acc / 16, o0) < 0.15  # unbiased: the 16-sample mean approaches the no-dropout output
+    a = _AttnPacked.apply(qkv.clone().requires_grad_(True), H, 0.1)
+    b = _AttnPacked.apply(qkv.clone().requires_grad_(True), H, 0.1)
+    assert not torch.equal(a, b)  # fresh mask per call
