@@ -28,6 +28,7 @@ struct Params {
     int64_t q_sb, q_ss, k_sb, k_ss, v_sb, v_ss;
     float scale, p_drop, inv_keep;
     uint32_t seed0, seed1, thr;
+    const uint64_t *seed_state;  // optional device-resident word mixed into the seed (advanced between hipGraph replays)
 };
 
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
@@ -54,6 +55,14 @@ __device__ __forceinline__ void store_row(uint16_t *p, const float in[HD]) {
         uint32_t w[4];
         for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f2bf(in[8 * c + 2 * e]) | ((uint32_t)f2bf(in[8 * c + 2 * e + 1]) << 16);
         p4[c] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+__device__ __forceinline__ void mix_seed_state(Params &P) {
+    if (P.seed_state) {
+        const uint64_t s = *P.seed_state;
+        P.seed0 ^= (uint32_t)s * 0x9E3779B1u;
+        P.seed1 += (uint32_t)(s >> 32) * 0x85EBCA77u + (uint32_t)s;
     }
 }
 
@@ -87,6 +96,7 @@ __device__ __forceinline__ void put_row(float *row, const float v[HD]) {
 
 // ------------------------------------------------------------------------------------------------ Sq = 17
 __global__ void __launch_bounds__(64) k_attn_fwd17(Params P, uint16_t *__restrict__ o, float *__restrict__ lse) {
+    mix_seed_state(P);
     __shared__ float Ks[PAIRS * PSTRIDE], Vs[PAIRS * PSTRIDE];
     const int lane = threadIdx.x, pl = lane / SK, i = lane - pl * SK;
     const int64_t pair = (int64_t)blockIdx.x * PAIRS + pl;
@@ -128,6 +138,7 @@ __global__ void __launch_bounds__(64) k_attn_fwd17(Params P, uint16_t *__restric
 __global__ void __launch_bounds__(64) k_attn_bwd17(Params P, const uint16_t *__restrict__ dout, const float *__restrict__ lse,
                                                    uint16_t *__restrict__ dq, uint16_t *__restrict__ dk,
                                                    uint16_t *__restrict__ dv) {
+    mix_seed_state(P);
     __shared__ float Ks[PAIRS * PSTRIDE], Vs[PAIRS * PSTRIDE], Qs[PAIRS * PSTRIDE], Gs[PAIRS * PSTRIDE];
     __shared__ float dSs[PAIRS * SK * (SK + 1)], Pt[PAIRS * SK * (SK + 1)];
     const int lane = threadIdx.x, pl = lane / SK, i = lane - pl * SK;
@@ -182,6 +193,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd17(Params P, const uint16_t *__r
 
 // ------------------------------------------------------------------------------------------------ Sq = 1 (CLS row)
 __global__ void __launch_bounds__(64) k_attn_fwd1(Params P, uint16_t *__restrict__ o, float *__restrict__ lse) {
+    mix_seed_state(P);
     const int64_t pair = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (pair >= P.B * P.H) return;
     const int64_t b = pair / P.H;
@@ -215,6 +227,7 @@ __global__ void __launch_bounds__(64) k_attn_fwd1(Params P, uint16_t *__restrict
 __global__ void __launch_bounds__(64) k_attn_bwd1(Params P, const uint16_t *__restrict__ dout, const float *__restrict__ lse,
                                                   uint16_t *__restrict__ dq, uint16_t *__restrict__ dk,
                                                   uint16_t *__restrict__ dv) {
+    mix_seed_state(P);
     const int64_t pair = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (pair >= P.B * P.H) return;
     const int64_t b = pair / P.H;
@@ -253,7 +266,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd1(Params P, const uint16_t *__re
 
 inline bool fill(Params &P, const void *q, const void *k, const void *v, int64_t B, int H, int Sq, int64_t q_sb,
                  int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, float scale, float p_drop,
-                 uint64_t seed) {
+                 uint64_t seed, const uint64_t *seed_state) {
     if (!q || !k || !v || B <= 0 || H <= 0 || (Sq != 1 && Sq != SK) || !(p_drop >= 0.f && p_drop < 1.f)) return false;
     // rows are read/written as 4 x 16 bytes
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return false;
@@ -262,7 +275,7 @@ inline bool fill(Params &P, const void *q, const void *k, const void *v, int64_t
     P.B = B; P.H = H;
     P.q_sb = q_sb; P.q_ss = q_ss; P.k_sb = k_sb; P.k_ss = k_ss; P.v_sb = v_sb; P.v_ss = v_ss;
     P.scale = scale; P.p_drop = p_drop; P.inv_keep = 1.0f / (1.0f - p_drop);
-    P.seed0 = (uint32_t)seed; P.seed1 = (uint32_t)(seed >> 32);
+    P.seed0 = (uint32_t)seed; P.seed1 = (uint32_t)(seed >> 32); P.seed_state = seed_state;
     P.thr = (uint32_t)(p_drop * 16777216.0f);
     return true;
 }
@@ -275,9 +288,9 @@ inline int done() {
 
 extern "C" int g2048_attn_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int H, int Sq,
                               int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss,
-                              float scale, float p_drop, uint64_t seed, void *stream) {
+                              float scale, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream) {
     Params P;
-    if (!o || !lse || ((uintptr_t)o & 15) || !fill(P, q, k, v, B, H, Sq, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, scale, p_drop, seed))
+    if (!o || !lse || ((uintptr_t)o & 15) || !fill(P, q, k, v, B, H, Sq, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, scale, p_drop, seed, seed_state))
         return G2048_EINVAL;
     const int64_t pairs = B * H;
     if (Sq == SK)
@@ -292,10 +305,10 @@ extern "C" int g2048_attn_fwd(const void *q, const void *k, const void *v, void 
 extern "C" int g2048_attn_bwd(const void *q, const void *k, const void *v, const void *dout, const float *lse, void *dq,
                               void *dk, void *dv, int64_t B, int H, int Sq, int64_t q_sb, int64_t q_ss, int64_t k_sb,
                               int64_t k_ss, int64_t v_sb, int64_t v_ss, float scale, float p_drop, uint64_t seed,
-                              void *stream) {
+                              const uint64_t *seed_state, void *stream) {
     Params P;
     if (!dout || !lse || !dq || !dk || !dv || (((uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) ||
-        !fill(P, q, k, v, B, H, Sq, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, scale, p_drop, seed))
+        !fill(P, q, k, v, B, H, Sq, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, scale, p_drop, seed, seed_state))
         return G2048_EINVAL;
     const int64_t pairs = B * H;
     if (Sq == SK)

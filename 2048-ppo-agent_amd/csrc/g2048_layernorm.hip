@@ -1,0 +1,253 @@
+// Fused residual-add + dropout + LayerNorm (+ bf16 cast) for the PPO update, forward and backward, d_model 256.
+//
+// In the pre-norm encoder layers of the policy (reference: nn.TransformerEncoderLayer(norm_first=True) built at
+// src/ppo/transformer_encoder.py:138-148) every sub-layer ends with `x = x + dropout(branch)` and the next one starts
+// with `h = LayerNorm(x)`; under bf16 autocast PyTorch runs that as dropout (bf16) + add (f32) + LayerNorm (f32) +
+// cast to bf16 for the next GEMM: four memory-bound kernels forward and six backward over [tokens, 256].  Here it is
+// one kernel each way: one wavefront per token row (4 features per lane, one 16-byte load), statistics by wave
+// reduction, dropout mask recomputed from (seed, element index) in the backward, gamma/beta gradients accumulated in
+// registers over the rows of a workgroup and flushed with one float atomic per column.
+//   x_new = x + dropout(a)                 (f32 residual stream; a = bf16 branch output, may be absent)
+//   h     = bf16( (x_new - mean) * rstd * gamma + beta )
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/g2048.h"
+
+namespace {
+
+constexpr int D = 256, ROWS_PER_BLOCK = 32, WAVES = 4;
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ bool keep_elem(uint32_t s0, uint32_t s1, uint32_t thr, uint64_t idx) {
+    uint32_t x = (uint32_t)idx * 0x9E3779B1u ^ s0;
+    x ^= (uint32_t)(idx >> 32) * 0x85EBCA77u + s1;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (x >> 8) >= thr;
+}
+__device__ __forceinline__ void mix_seed_state(const uint64_t *seed_state, uint32_t &s0, uint32_t &s1) {
+    if (seed_state) {
+        const uint64_t s = *seed_state;
+        s0 ^= (uint32_t)s * 0x9E3779B1u;
+        s1 += (uint32_t)(s >> 32) * 0x85EBCA77u + (uint32_t)s;
+    }
+}
+__device__ __forceinline__ float bf2f(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+    const __bf16 b = (__bf16)f;
+    return *reinterpret_cast<const uint16_t *>(&b);
+}
+
+// x: f32 rows of 256 with row stride x_rs (elements); a: bf16 [T][256] or null; outputs contiguous [T][256]
+__global__ void __launch_bounds__(64 * WAVES)
+k_add_ln_fwd(const float *__restrict__ x, int64_t x_rs, const uint16_t *__restrict__ a, const float *__restrict__ gamma,
+             const float *__restrict__ beta, float *__restrict__ x_new, uint16_t *__restrict__ h,
+             float *__restrict__ mean_out, float *__restrict__ rstd_out, int64_t T, float eps, float inv_keep,
+             uint32_t thr, uint32_t s0, uint32_t s1, const uint64_t *seed_state) {
+    mix_seed_state(seed_state, s0, s1);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float4 g = reinterpret_cast<const float4 *>(gamma)[lane], bt = reinterpret_cast<const float4 *>(beta)[lane];
+    for (int64_t row = (int64_t)blockIdx.x * WAVES + w; row < T; row += (int64_t)gridDim.x * WAVES) {
+        float4 v = reinterpret_cast<const float4 *>(x + row * x_rs)[lane];
+        if (a) {
+            const uint2 ab = reinterpret_cast<const uint2 *>(a + row * D)[lane];
+            float av[4] = {bf2f(ab.x & 0xFFFFu), bf2f(ab.x >> 16), bf2f(ab.y & 0xFFFFu), bf2f(ab.y >> 16)};
+            if (thr) {
+                const uint64_t base = (uint64_t)row * D + 4 * lane;
+                for (int q = 0; q < 4; ++q) av[q] = keep_elem(s0, s1, thr, base + q) ? av[q] * inv_keep : 0.0f;
+            }
+            v.x += av[0]; v.y += av[1]; v.z += av[2]; v.w += av[3];
+            reinterpret_cast<float4 *>(x_new + row * D)[lane] = v;
+        }
+        const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / D);
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        const float rstd = rsqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / D) + eps);
+        const uint32_t lo = f2bf(dx * rstd * g.x + bt.x) | (f2bf(dy * rstd * g.y + bt.y) << 16);
+        const uint32_t hi = f2bf(dz * rstd * g.z + bt.z) | (f2bf(dw * rstd * g.w + bt.w) << 16);
+        reinterpret_cast<uint2 *>(h + row * D)[lane] = make_uint2(lo, hi);
+        if (lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+    }
+}
+
+// xn: the tensor that was normalised (x_new, or x itself when there was no branch), row stride xn_rs.
+// g_x: gradient flowing into x_new from the residual stream (f32 [T][256], may be null); g_h: bf16 [T][256].
+// dx (f32 [T][256]) = g_x + dLN;  da (bf16 [T][256], may be null) = dropout-masked dx.
+__global__ void __launch_bounds__(64 * WAVES)
+k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restrict__ g_x, const uint16_t *__restrict__ g_h,
+             const float *__restrict__ mean_in, const float *__restrict__ rstd_in, const float *__restrict__ gamma,
+             float *__restrict__ dx, uint16_t *__restrict__ da, float *__restrict__ dgamma, float *__restrict__ dbeta,
+             int64_t T, float inv_keep, uint32_t thr, uint32_t s0, uint32_t s1, const uint64_t *seed_state) {
+    mix_seed_state(seed_state, s0, s1);
+    __shared__ float red[WAVES][2][D];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float4 g = reinterpret_cast<const float4 *>(gamma)[lane];
+    float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+    for (int r = w; r < ROWS_PER_BLOCK; r += WAVES) {
+        const int64_t row = row0 + r;
+        if (row >= T) break;
+        const float4 v = reinterpret_cast<const float4 *>(xn + row * xn_rs)[lane];
+        const uint2 gb = reinterpret_cast<const uint2 *>(g_h + row * D)[lane];
+        const float gh[4] = {bf2f(gb.x & 0xFFFFu), bf2f(gb.x >> 16), bf2f(gb.y & 0xFFFFu), bf2f(gb.y >> 16)};
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const float xh[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+        float dxh[4], s1sum = 0.f, s2sum = 0.f;
+        for (int q = 0; q < 4; ++q) {
+            dxh[q] = gh[q] * gg[q];
+            s1sum += dxh[q];
+            s2sum += dxh[q] * xh[q];
+            dg[q] += gh[q] * xh[q];
+            db[q] += gh[q];
+        }
+        const float c1 = wave_sum(s1sum) * (1.0f / D), c2 = wave_sum(s2sum) * (1.0f / D);
+        float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_x) gx = reinterpret_cast<const float4 *>(g_x + row * D)[lane];
+        float o[4] = {gx.x, gx.y, gx.z, gx.w};
+        for (int q = 0; q < 4; ++q) o[q] += rstd * (dxh[q] - c1 - xh[q] * c2);
+        reinterpret_cast<float4 *>(dx + row * D)[lane] = make_float4(o[0], o[1], o[2], o[3]);
+        if (da) {
+            if (thr) {
+                const uint64_t base = (uint64_t)row * D + 4 * lane;
+                for (int q = 0; q < 4; ++q) o[q] = keep_elem(s0, s1, thr, base + q) ? o[q] * inv_keep : 0.0f;
+            }
+            reinterpret_cast<uint2 *>(da + row * D)[lane] = make_uint2(f2bf(o[0]) | (f2bf(o[1]) << 16), f2bf(o[2]) | (f2bf(o[3]) << 16));
+        }
+    }
+    for (int q = 0; q < 4; ++q) {
+        red[w][0][4 * lane + q] = dg[q];
+        red[w][1][4 * lane + q] = db[q];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += 64 * WAVES) {
+        const int which = c / D, col = c - which * D;
+        float s = 0.f;
+        for (int ww = 0; ww < WAVES; ++ww) s += red[ww][which][col];
+        atomicAdd((which ? dbeta : dgamma) + col, s);
+    }
+}
+
+inline int done() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(1000 + (int)e);
+}
+
+}  // namespace
+
+extern "C" int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void *a, const float *gamma, const float *beta,
+                                float *x_new, void *h, float *mean, float *rstd, int64_t T, float eps, float p_drop,
+                                uint64_t seed, const uint64_t *seed_state, void *stream) {
+    if (!x || !gamma || !beta || !h || !mean || !rstd || T <= 0 || (a && !x_new) || !(p_drop >= 0.f && p_drop < 1.f) ||
+        (x_row_stride & 3) || (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)x_new) & 15) ||
+        (((uintptr_t)a | (uintptr_t)h) & 7))
+        return G2048_EINVAL;
+    const uint32_t thr = a ? (uint32_t)(p_drop * 16777216.0f) : 0u;
+    const int64_t blocks = (T + WAVES - 1) / WAVES;
+    hipLaunchKernelGGL(k_add_ln_fwd, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(64 * WAVES), 0, (hipStream_t)stream, x,
+                       x_row_stride, (const uint16_t *)a, gamma, beta, x_new, (uint16_t *)h, mean, rstd, T, eps,
+                       1.0f / (1.0f - p_drop), thr, (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
+    return done();
+}
+
+extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
+                                const float *rstd, const float *gamma, float *dx, void *da, float *dgamma, float *dbeta,
+                                int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream) {
+    if (!x_norm || !g_h || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || T <= 0 || (x_row_stride & 3) ||
+        !(p_drop >= 0.f && p_drop < 1.f) || (((uintptr_t)x_norm | (uintptr_t)g_x | (uintptr_t)dx | (uintptr_t)gamma) & 15) ||
+        (((uintptr_t)g_h | (uintptr_t)da) & 7))
+        return G2048_EINVAL;
+    const uint32_t thr = da ? (uint32_t)(p_drop * 16777216.0f) : 0u;
+    const int64_t blocks = (T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(k_add_ln_bwd, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream, x_norm, x_row_stride, g_x,
+                       (const uint16_t *)g_h, mean, rstd, gamma, dx, (uint16_t *)da, dgamma, dbeta, T, 1.0f / (1.0f - p_drop),
+                       thr, (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
+    return done();
+}
+
+// ---- column sums (bias gradients) ------------------------------------------------------------------------------------
+// out[c] = sum over rows of x[r][c], x bf16 or f32 [T][N] (row stride in elements), f32 accumulation, fixed summation
+// order (bit-reproducible).  Two launches: per-workgroup partial sums of an interleaved subset of the rows, then one
+// pass over the partials.  Replaces at::sum(dim=0) in the backward of every Linear of the update: that kernel's
+// cross-workgroup stage relies on a memset of its semaphores, which a replayed hipGraph does not reproduce reliably on
+// this stack (bias gradients differ from eager on every batch but the captured one, tools/debug_graph_grads.py).
+namespace {
+
+constexpr int CS_THREADS = 256, CS_VEC = 4;
+
+template <bool BF16>
+__global__ void __launch_bounds__(CS_THREADS)
+k_colsum_partial(const void *__restrict__ x, int64_t rs, int64_t T, int N, float *__restrict__ partial) {
+    __shared__ float red[CS_THREADS][CS_VEC];
+    const int cols_v = N / CS_VEC, rows_per_pass = CS_THREADS / cols_v;
+    const int cv = threadIdx.x % cols_v, rr = threadIdx.x / cols_v;
+    float acc[CS_VEC] = {0.f, 0.f, 0.f, 0.f};
+    if (rr < rows_per_pass) {
+        for (int64_t r = (int64_t)blockIdx.x * rows_per_pass + rr; r < T; r += (int64_t)gridDim.x * rows_per_pass) {
+            if (BF16) {
+                const uint2 v = *reinterpret_cast<const uint2 *>((const uint16_t *)x + r * rs + CS_VEC * cv);
+                acc[0] += bf2f(v.x & 0xFFFFu); acc[1] += bf2f(v.x >> 16); acc[2] += bf2f(v.y & 0xFFFFu); acc[3] += bf2f(v.y >> 16);
+            } else {
+                const float4 v = *reinterpret_cast<const float4 *>((const float *)x + r * rs + CS_VEC * cv);
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            }
+        }
+    }
+    for (int q = 0; q < CS_VEC; ++q) red[threadIdx.x][q] = acc[q];
+    __syncthreads();
+    if (rr == 0) {
+        for (int k = 1; k < rows_per_pass; ++k)
+            for (int q = 0; q < CS_VEC; ++q) acc[q] += red[threadIdx.x + k * cols_v][q];
+        reinterpret_cast<float4 *>(partial + (int64_t)blockIdx.x * N)[cv] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_colsum_final(const float *__restrict__ partial, int G, int N, float *__restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {
+        s0 += partial[(int64_t)g * N + c];
+        s1 += partial[(int64_t)(g + 1) * N + c];
+        s2 += partial[(int64_t)(g + 2) * N + c];
+        s3 += partial[(int64_t)(g + 3) * N + c];
+    }
+    for (; g < G; ++g) s0 += partial[(int64_t)g * N + c];
+    out[c] = (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace
+
+extern "C" int g2048_colsum_workspace_floats(int64_t T, int N) {
+    if (T <= 0 || N <= 0) return G2048_EINVAL;
+    return G2048_COLSUM_MAX_GROUPS * N;
+}
+
+extern "C" int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int64_t T, int N, float *workspace, float *out,
+                            void *stream) {
+    if (!x || !workspace || !out || T <= 0 || N < CS_VEC || N % CS_VEC || N / CS_VEC > CS_THREADS || row_stride % CS_VEC ||
+        ((uintptr_t)x & (is_bf16 ? 7 : 15)) || ((uintptr_t)workspace & 15))
+        return G2048_EINVAL;
+    const int rows_per_pass = CS_THREADS / (N / CS_VEC);
+    int64_t G = (T + rows_per_pass - 1) / rows_per_pass;
+    // at least ~32 rows per workgroup, at most MAX_GROUPS workgroups
+    G = (G + 31) / 32;
+    if (G > G2048_COLSUM_MAX_GROUPS) G = G2048_COLSUM_MAX_GROUPS;
+    if (G < 1) G = 1;
+    if (is_bf16)
+        hipLaunchKernelGGL(k_colsum_partial<true>, dim3((unsigned)G), dim3(CS_THREADS), 0, (hipStream_t)stream, x, row_stride, T, N,
+                           workspace);
+    else
+        hipLaunchKernelGGL(k_colsum_partial<false>, dim3((unsigned)G), dim3(CS_THREADS), 0, (hipStream_t)stream, x, row_stride, T, N,
+                           workspace);
+    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, (int)G, N,
+                       out);
+    return done();
+}

@@ -43,9 +43,14 @@ SIGNATURES = {
     "g2048_compact": [_vp] * 14 + [_i64, _i64, _vp],
     "g2048_policy_encoder": [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp],
     "g2048_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, C.c_float,
-                       C.c_float, C.c_uint64, _vp],
+                       C.c_float, C.c_uint64, _vp, _vp],
     "g2048_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,
-                       C.c_float, C.c_float, C.c_uint64, _vp],
+                       C.c_float, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_add_ln_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_colsum_workspace_floats": [_i64, _i32],
+    "g2048_colsum": [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp],
+    "g2048_add_ln_bwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp,
+                         _vp],
 }
 
 _lib = None
@@ -250,17 +255,57 @@ def policy_encoder(boards, embed_table, cls_token, weights_bf16, params_f32, n_l
 
 
 def attn_fwd(q_ptr: int, k_ptr: int, v_ptr: int, o, lse, B: int, H: int, Sq: int, strides, scale: float, p_drop: float,
-             seed: int):
+             seed: int, seed_state: int = 0):
     """q/k/v: raw device addresses inside bf16 tensors the caller keeps alive; strides = (q_sb, q_ss, k_sb, k_ss,
     v_sb, v_ss) in elements."""
     _check(load().g2048_attn_fwd(q_ptr, k_ptr, v_ptr, _dev(o, torch.bfloat16, B * Sq * H * 32, "o"),
                                  _dev(lse, f32, B * H * Sq, "lse"), B, H, Sq, *[int(x) for x in strides], float(scale),
-                                 float(p_drop), int(seed), _stream()), "g2048_attn_fwd")
+                                 float(p_drop), int(seed), seed_state or None, _stream()), "g2048_attn_fwd")
 
 
 def attn_bwd(q_ptr: int, k_ptr: int, v_ptr: int, dout, lse, dq_ptr: int, dk_ptr: int, dv_ptr: int, B: int, H: int,
-             Sq: int, strides, scale: float, p_drop: float, seed: int):
+             Sq: int, strides, scale: float, p_drop: float, seed: int, seed_state: int = 0):
     _check(load().g2048_attn_bwd(q_ptr, k_ptr, v_ptr, _dev(dout, torch.bfloat16, B * Sq * H * 32, "dout"),
                                  _dev(lse, f32, B * H * Sq, "lse"), dq_ptr, dk_ptr, dv_ptr, B, H, Sq,
-                                 *[int(x) for x in strides], float(scale), float(p_drop), int(seed), _stream()),
-           "g2048_attn_bwd")
+                                 *[int(x) for x in strides], float(scale), float(p_drop), int(seed), seed_state or None,
+                                 _stream()), "g2048_attn_bwd")
+
+
+def add_ln_fwd(x_ptr: int, x_row_stride: int, a, gamma, beta, x_new, h, mean, rstd, T: int, eps: float, p_drop: float,
+               seed: int, seed_state: int = 0):
+    """x_ptr: raw device address of f32 rows (stride x_row_stride elements) the caller keeps alive."""
+    bf = torch.bfloat16
+    _check(load().g2048_add_ln_fwd(x_ptr, int(x_row_stride), _dev(a, bf, 256 * T, "a", optional=True),
+                                   _dev(gamma, f32, 256, "gamma"), _dev(beta, f32, 256, "beta"),
+                                   _dev(x_new, f32, 256 * T, "x_new", optional=True), _dev(h, bf, 256 * T, "h"),
+                                   _dev(mean, f32, T, "mean"), _dev(rstd, f32, T, "rstd"), T, float(eps), float(p_drop),
+                                   int(seed), seed_state or None, _stream()), "g2048_add_ln_fwd")
+
+
+def add_ln_bwd(xn_ptr: int, x_row_stride: int, g_x, g_h, mean, rstd, gamma, dx, da, dgamma, dbeta, T: int,
+               p_drop: float, seed: int, seed_state: int = 0):
+    bf = torch.bfloat16
+    _check(load().g2048_add_ln_bwd(xn_ptr, int(x_row_stride), _dev(g_x, f32, 256 * T, "g_x", optional=True),
+                                   _dev(g_h, bf, 256 * T, "g_h"), _dev(mean, f32, T, "mean"), _dev(rstd, f32, T, "rstd"),
+                                   _dev(gamma, f32, 256, "gamma"), _dev(dx, f32, 256 * T, "dx"),
+                                   _dev(da, bf, 256 * T, "da", optional=True), _dev(dgamma, f32, 256, "dgamma"),
+                                   _dev(dbeta, f32, 256, "dbeta"), T, float(p_drop), int(seed), seed_state or None,
+                                   _stream()),
+           "g2048_add_ln_bwd")
+
+
+COLSUM_MAX_GROUPS = 1024
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """f32 column sums of a 2-D bf16/f32 device tensor whose rows are contiguous (any row stride)."""
+    if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (torch.bfloat16, f32):
+        raise NativeError(f"colsum: expected a 2-D bf16/f32 device tensor with contiguous rows, got {x.dtype} {tuple(x.shape)} "
+                          f"strides {x.stride()}")
+    T, N = x.shape
+    if out is None:
+        out = torch.empty(N, dtype=f32, device=x.device)
+    ws = torch.empty(COLSUM_MAX_GROUPS * N, dtype=f32, device=x.device)
+    _check(load().g2048_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), x.stride(0), T, N, ws.data_ptr(),
+                               _dev(out, f32, N, "out"), _stream()), "g2048_colsum")
+    return out

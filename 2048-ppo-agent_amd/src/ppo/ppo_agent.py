@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from torch.distributions import Categorical
 
 from ..env_definitions import ACTION_DIM, OBS_DIM
-from .transformer_encoder import TransformerEncoder
+from .transformer_encoder import Bf16Shadow, TransformerEncoder, _linear, _train_bf16
 
 
 def _one_hot(boards: torch.Tensor, classes: int, dtype) -> torch.Tensor:
@@ -28,16 +28,41 @@ def _head(d_in: int, hidden: int, d_out: int) -> nn.Sequential:
 class _ActorCritic(nn.Module):
     """Shared action/evaluation logic over ``features(observations) -> [B, d]``."""
 
+    # every large row reduction of the bf16 update (bias gradients) goes through g2048_colsum, so forward+backward
+    # can be replayed from a hipGraph (at::sum's cross-workgroup stage does not survive a replay on this stack)
+    hip_graph_safe = True
+
     def features(self, observations: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
+    _head_shadow = None
+
+    def _heads(self, feats: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(actor(feats), critic(feats)); on the update path (bf16 autocast with gradients) the Linear layers read
+        pre-cast bf16 shadows of their weights and produce f32 gradients directly (``_LinearSplitK``)."""
+        lins = [m for head in (self.actor, self.critic) for m in head if isinstance(m, nn.Linear)]
+        if not _train_bf16(feats, lins[0].weight):
+            return self.actor(feats), self.critic(feats)
+        if self._head_shadow is None:
+            self._head_shadow = Bf16Shadow([p for m in lins for p in (m.weight, m.bias) if p is not None])
+        views = iter(self._head_shadow())
+        outs = []
+        for head in (self.actor, self.critic):
+            x = feats
+            for m in head:
+                if isinstance(m, nn.Linear):
+                    x = _linear(x, m.weight, m.bias, next(views), None if m.bias is None else next(views))
+                else:
+                    x = m(x)
+            outs.append(x)
+        return outs[0], outs[1]
+
     def forward(self, observations: torch.Tensor, action_mask: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (action_logits [B, action_dim], values [B, 1]); masked actions get ``logit - 1e8``."""
-        feats = self.features(observations)
-        logits = self.actor(feats)
+        logits, values = self._heads(self.features(observations))
         if action_mask is not None:
             logits = logits - 1e8 * (1 - action_mask.float())
-        return logits, self.critic(feats)
+        return logits, values
 
     def get_action(self, observations, action_mask=None):
         """Sample -> (actions, log_probs, values)."""
@@ -100,8 +125,9 @@ class MLPAgent(_ActorCritic):
     def features(self, observations):
         if observations.dtype in (torch.uint8, torch.int16, torch.int32, torch.int64):
             if torch.is_grad_enabled() and self.trunk_in.weight.requires_grad:
-                h = self.trunk_in(_one_hot(observations, self.observation_dim, self.trunk_in.weight.dtype).flatten(1))
-                return F.relu(self.trunk_hidden(F.relu(h)))
+                oh = _one_hot(observations, self.observation_dim, self.trunk_in.weight.dtype).flatten(1)
+                h = F.relu(_linear(oh, self.trunk_in.weight, self.trunk_in.bias))
+                return F.relu(_linear(h, self.trunk_hidden.weight, self.trunk_hidden.bias))
             # inference: one-hot @ W^T == sum over cells of the selected weight columns
             cols = observations.long() + torch.arange(self.board_cells, device=observations.device) * self.observation_dim
             h = F.embedding(cols, self.trunk_in.weight.t()).sum(dim=1) + self.trunk_in.bias

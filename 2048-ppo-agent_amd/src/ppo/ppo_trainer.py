@@ -25,6 +25,7 @@ from ..runs.batch_runner import BatchRunner
 from .data_loader import DeviceBatches, PPODataset
 from .rollout_buffer import RolloutBuffer
 from .torch_action_wrapper import TorchActionFunction
+from .transformer_encoder import Bf16Shadow, graph_seed_state
 
 logger = logging.getLogger(__name__)
 
@@ -72,7 +73,8 @@ class _GraphedFwdBwd:
 
     Inputs are copied into static buffers, the graph is replayed, gradients land in static ``.grad`` tensors
     (or in the flat all-reduce bucket when it exists); clipping, the optimizer and the LR schedule stay eager.
-    Dropout draws fresh masks on every replay (graph-safe philox offsets)."""
+    Build it while no autograd graph over the agent's parameters is alive (see ``PPOTrainer._eager_fwd_bwd``).
+    Dropout draws fresh masks on every replay (philox offsets for PyTorch's kernels, ``graph_seed_state`` for ours)."""
 
     def __init__(self, trainer: "PPOTrainer", M: int, sample: dict):
         self.tr, self.M = trainer, M
@@ -87,13 +89,22 @@ class _GraphedFwdBwd:
                 self._zero()
                 self._fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
-        if trainer._flat_grad is None:
-            trainer.optimizer.zero_grad(set_to_none=True)  # backward inside the capture creates static grads
+        trainer.optimizer.zero_grad(set_to_none=True)  # backward inside the capture creates the (static) gradients
         self.graph = torch.cuda.CUDAGraph()
+        Bf16Shadow.invalidate_all()  # the bf16 weight refresh must be part of the graph
+        seed_word = graph_seed_state(dev)  # allocated outside the capture
         with torch.cuda.graph(self.graph):
-            if trainer._flat_grad is not None:
-                trainer._flat_grad.zero_()
+            seed_word.add_(1)  # new dropout masks on every replay (the HIP kernels read it at run time)
             self.out = self._fwd_bwd()
+            if trainer._flat_grad is not None:
+                trainer._collect_grads(point_grads=False)  # graph-owned gradients -> all-reduce bucket, one copy
+        Bf16Shadow.invalidate_all()  # nothing was copied during the capture itself
+        # the gradients the replay writes (graph pool) / the tensors the optimizer reads after a replay
+        self.grads = [p.grad for p in trainer.agent.parameters()]
+        if trainer._flat_grad is not None:
+            for p, v in zip(trainer._params, trainer._flat_views):
+                p.grad = v
+            self.grads = [p.grad for p in trainer.agent.parameters()]
 
     def _zero(self):
         self.tr._zero_grad()
@@ -119,6 +130,8 @@ class _GraphedFwdBwd:
         for k, v in batch.items():
             self.static[k].copy_(v)
         self.graph.replay()
+        for p, g in zip(self.tr.agent.parameters(), self.grads):  # an eager step in between may have re-pointed them
+            p.grad = g
         return self.out
 
 
@@ -129,7 +142,7 @@ class PPOTrainer:
                  target_kl: float = 0.01, use_action_mask: bool = False, device: torch.device = torch.device("cpu"),
                  mixed_precision: Optional[Literal["float16", "bfloat16"]] = "bfloat16",
                  max_samples_per_epoch: int = None, shuffle_on_reset: bool = False, rollout_amp: bool = False,
-                 log_dir: str = "logs", use_hip_graph: bool = False):
+                 log_dir: str = "logs", use_hip_graph: Optional[bool] = None):
         self.agent = agent.to(device)
         self.batch_runner = batch_runner
         self.rollout_buffer = rollout_buffer
@@ -164,15 +177,17 @@ class PPOTrainer:
             self._bind_flat_grads()
             self._broadcast_parameters()
 
-        # OPT-IN: forward + loss + backward of one minibatch replayed as a hipGraph (-25 % per minibatch of 2048,
-        # ~300 small kernels).  Off by default: on ROCm 7.2 / torch 2.10 the replayed graph yields non-finite
-        # bias gradients under bf16 autocast (fp32 is fine; tools/debug_nan.py reproduces it), so it is only
-        # safe with mixed_precision=None.  Built lazily per minibatch size, see _GraphedFwdBwd.
+        # forward + loss + backward of one minibatch replayed as a hipGraph: the update is ~330 small kernels per
+        # minibatch and launch-bound in eager mode (7.0 ms of host time for 4.7 ms of GPU work at minibatch 2048).
+        # Default (None): on for the bf16 update of agents whose large row reductions all run through g2048_colsum
+        # (``hip_graph_safe``): at::sum's cross-workgroup stage zeroes its semaphores with a memset that a replayed
+        # hipGraph does not reproduce on ROCm 7.2 / torch 2.10 (wrong bias gradients on every batch but the
+        # captured one; tools/debug_graph_grads.py).  Built lazily per minibatch size, see _GraphedFwdBwd.
+        if use_hip_graph is None:
+            use_hip_graph = (self.use_amp and self.amp_dtype == torch.bfloat16
+                             and getattr(self.agent, "hip_graph_safe", False))
         self.use_hip_graph = bool(use_hip_graph) and self.device.type == "cuda"
         self._graphs = {}
-        if self.use_hip_graph and self._flat_grad is None:
-            # static gradient memory for the graph: backward accumulates in place into views of one bucket
-            self._bind_flat_grads()
 
         self.writer = _make_writer(log_dir) if self.rank == 0 else _NullWriter()
         self.total_timesteps = 0
@@ -187,29 +202,43 @@ class PPOTrainer:
 
     # ------------------------------------------------------------------ multi-GPU plumbing
     def _bind_flat_grads(self):
-        """One contiguous gradient bucket; every p.grad is a view into it -> a single all-reduce per step."""
-        params = [p for p in self.agent.parameters() if p.requires_grad]
-        total = sum(p.numel() for p in params)
+        """One contiguous gradient bucket for the single all-reduce per step; ``_flat_views[i]`` is the slice of
+        parameter i.  Backward writes fresh ``.grad`` tensors (no accumulate kernel per parameter) which
+        ``_collect_grads`` gathers into the bucket with one multi-tensor copy and then re-points ``.grad`` at."""
+        self._params = [p for p in self.agent.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in self._params)
         self._flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
-        off = 0
-        for p in params:
+        self._flat_views, off = [], 0
+        for p in self._params:
             n = p.numel()
-            p.grad = self._flat_grad[off:off + n].view_as(p)
+            self._flat_views.append(self._flat_grad[off:off + n].view_as(p))
+            p.grad = None
             off += n
+
+    def _collect_grads(self, point_grads: bool = True):
+        src, dst = [], []
+        for p, v in zip(self._params, self._flat_views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+            if point_grads:
+                p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
 
     def _broadcast_parameters(self):
         for t in list(self.agent.parameters()) + list(self.agent.buffers()):
             dist.broadcast(t.data, src=0, group=self._group)
 
     def _zero_grad(self):
-        if self._flat_grad is not None:
-            self._flat_grad.zero_()
-        else:
-            # once a hipGraph owns the .grad tensors they must stay allocated (the replay writes into them)
-            self.optimizer.zero_grad(set_to_none=not self._graphs)
+        # fresh gradients every step: backward then writes them without an accumulate kernel per parameter
+        self.optimizer.zero_grad(set_to_none=True)
 
     def _allreduce_grads(self):
         if self.world > 1:
+            self._collect_grads()  # no-op for gradients that already live in the bucket (hipGraph replay)
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self._group)
             self._flat_grad.div_(self.world)
 
@@ -290,6 +319,26 @@ class PPOTrainer:
         loss = (policy_loss + self.value_loss_coef * value_loss + self.entropy_coef * entropy_loss).mean()
         return loss, policy_loss, value_loss, entropy_loss, new_log_probs
 
+    def _eager_fwd_bwd(self, obs, actions, masks, old_lp, adv, ret):
+        """Forward + loss + (scaled) backward of one minibatch -> (stats [4] f64, kl [1] f64), both detached.  Nothing
+        that references the autograd graph leaves this frame: a live graph keeps the parameters' AccumulateGrad nodes
+        (and the stream they were created on) alive, and a later hipGraph capture on another stream would then have
+        to synchronise with that stream, which breaks the capture."""
+        if self.use_amp:
+            with autocast(device_type="cuda", dtype=self.amp_dtype):
+                loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
+        else:
+            loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
+        self._zero_grad()
+        if self.use_amp:
+            self.scaler.scale(loss).backward()
+        else:
+            loss.backward()
+        with torch.no_grad():
+            stats = torch.stack([pl.mean(), vl.mean(), el.mean(), loss.detach()]).double()
+            kl = (old_lp - new_lp).mean().double()
+        return stats, kl
+
     def _unpack_batch(self, batch):
         obs = batch["observations"]
         actions = batch["actions"]
@@ -338,19 +387,7 @@ class PPOTrainer:
                     graphed = self._graphs[gkey]
                     stats, kl = graphed.run(sample)
                 else:
-                    if self.use_amp:
-                        with autocast(device_type="cuda", dtype=self.amp_dtype):
-                            loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
-                    else:
-                        loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
-                    self._zero_grad()
-                    if self.use_amp:
-                        self.scaler.scale(loss).backward()
-                    else:
-                        loss.backward()
-                    with torch.no_grad():
-                        stats = torch.stack([pl.mean(), vl.mean(), el.mean(), loss.detach()]).double()
-                        kl = (old_lp - new_lp).mean().double()
+                    stats, kl = self._eager_fwd_bwd(obs, actions, masks, old_lp, adv, ret)
                 self._allreduce_grads()
                 if self.use_amp:
                     self.scaler.unscale_(self.optimizer)

@@ -6,6 +6,7 @@ out explicitly (pre-norm layers over fused QKV + SDPA) so the rollout and update
 can be captured in hipGraphs.  The GEMMs run on MFMA through hipBLASLt.
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -14,22 +15,104 @@ import torch.nn.functional as F
 from ..env_definitions import BOARD_DIM
 
 
-class _LinearSplitK(torch.autograd.Function):
-    """``F.linear`` under bf16 autocast whose WEIGHT gradient is a split-K product.
+class Bf16Shadow:
+    """bf16 copies of a list of f32 master parameters inside one flat buffer, refreshed by ONE multi-tensor copy
+    whenever a master changed (in-place updates bump ``Tensor._version``; a re-allocated master changes the data
+    pointer).  Under autocast every minibatch otherwise re-casts each weight and bias with its own 4-microsecond kernel
+    (about 50 launches per PPO minibatch, and the update is launch-bound)."""
 
-    dW = dY^T X reduces over every token of the minibatch (34 816 at minibatch 2048) into a tiny [out, in] matrix;
-    hipBLASLt runs that as 16-64 workgroups on 256 CUs (177 us per GEMM).  Cutting the token axis into 16 slices turns
-    it into a batched GEMM with 16x the workgroups plus an f32 sum of the partials: 42 us, 4x faster, and the f32 sum is
-    at least as accurate as the single bf16-output GEMM it replaces (tools/probe_splitk.py).  Forward, dX and the
-    bias gradient are exactly what autocast does."""
+    _live = weakref.WeakSet()
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.key, self.flat, self.views = None, None, None
+        Bf16Shadow._live.add(self)
+
+    def invalidate(self):
+        self.key = None
+
+    @staticmethod
+    def invalidate_all():
+        """Force the next use of every shadow to re-copy (called before a hipGraph capture so that the copy becomes
+        part of the graph: a replay runs no Python and would otherwise read stale shadows)."""
+        for s in list(Bf16Shadow._live):
+            s.invalidate()
+
+    def __call__(self):
+        ps = self.params
+        key = (ps[0].data_ptr(), sum(p._version for p in ps))
+        if key != self.key:
+            if self.flat is None or self.flat.device != ps[0].device:
+                offs, n = [], 0
+                for q in ps:
+                    offs.append(n)
+                    n += (q.numel() + 63) // 64 * 64  # keep every view 128-byte aligned for the GEMMs
+                self.flat = torch.empty(n, dtype=torch.bfloat16, device=ps[0].device)
+                self.views = [self.flat[o:o + q.numel()].view(q.shape) for o, q in zip(offs, ps)]
+            with torch.no_grad():
+                torch._foreach_copy_(self.views, [q.detach() for q in ps])
+            self.key = key
+        return self.views
+
+
+def _sum_f32(t: torch.Tensor, dim: int = 0) -> torch.Tensor:
+    return torch.sum(t, dim, dtype=torch.float32)
+
+
+def _colsum(t: torch.Tensor, out=None) -> torch.Tensor:
+    """f32 column sums of a [rows, N] device tensor (bias gradients): ``g2048_colsum`` (fixed summation order and safe
+    inside a replayed hipGraph, unlike at::sum's semaphore-based cross-workgroup stage) when the shape allows."""
+    N = t.shape[-1]
+    if t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and N % 4 == 0 and N <= 1024 and t.stride(0) % 4 == 0 \
+            and t.dtype in (torch.bfloat16, torch.float32):
+        from ..g2048 import native as nv
+
+        return nv.colsum(t, out)
+    if out is None:
+        return _sum_f32(t)
+    return torch.sum(t, 0, dtype=torch.float32, out=out)
+
+
+class _ExpandRows(torch.autograd.Function):
+    """``t.expand(B, -1, -1)`` of a [1, 1, D] parameter whose gradient (a sum over B rows) goes through ``_colsum``."""
+
+    @staticmethod
+    def forward(ctx, t, B):
+        return t.expand(B, -1, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _colsum(g.reshape(g.shape[0], -1)).view(1, 1, -1), None
+
+
+def _dweight(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """dW = dY^T X in f32 from bf16 operands.  It reduces over every token of the minibatch (34 816 at minibatch 2048)
+    into a tiny [out, in] matrix; hipBLASLt runs that as 16-64 workgroups on 256 CUs (177 us per GEMM).  Cutting the
+    token axis into 16 slices turns it into a batched GEMM with 16x the workgroups plus an f32 sum of the partials:
+    42 us, 4x faster, and the f32 sum is at least as accurate as the single bf16-output GEMM it replaces
+    (tools/probe_splitk.py)."""
+    T, S = x2.shape[0], _LinearSplitK.SLICES
+    if T % S == 0 and T // S >= 1024:
+        return _sum_f32(torch.bmm(dy2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1)))
+    return (dy2.t() @ x2).float()
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """``F.linear`` in bf16 (what autocast does) with a split-K weight gradient (``_dweight``), f32 gradients for the f32
+    master weight/bias produced directly by the reductions, and optional pre-cast bf16 shadows ``wb``/``bb`` of the
+    masters (``Bf16Shadow``) so that no cast kernels run per call."""
 
     SLICES = 16
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, wb=None, bb=None):
         with torch.autocast("cuda", enabled=False):
-            xb, wb = x.to(torch.bfloat16), weight.to(torch.bfloat16)
-            y = F.linear(xb, wb, None if bias is None else bias.to(torch.bfloat16))
+            xb = x.to(torch.bfloat16)
+            if wb is None:
+                wb = weight.to(torch.bfloat16)
+            if bias is not None and bb is None:
+                bb = bias.to(torch.bfloat16)
+            y = F.linear(xb, wb, bb)
         ctx.save_for_backward(xb, wb)
         ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
         return y
@@ -41,18 +124,68 @@ class _LinearSplitK(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16)
             x2 = xb.reshape(-1, xb.shape[-1])
-            T, S = x2.shape[0], _LinearSplitK.SLICES
             dx = (dy2 @ wb).view(xb.shape).to(x_dtype) if ctx.needs_input_grad[0] else None
-            if T % S == 0 and T // S >= 1024:
-                dw = torch.bmm(dy2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1)).float().sum(0)
-            else:
-                dw = dy2.t() @ x2
-            db = None if b_dtype is None else dy2.sum(0).to(b_dtype)
-        return dx, dw.to(w_dtype), db
+            dw = _dweight(dy2, x2).to(w_dtype)
+            db = None if b_dtype is None else _colsum(dy2).to(b_dtype)
+        return dx, dw, db, None, None
+
+
+class _InProjCls(torch.autograd.Function):
+    """in_proj of the LAST layer when only the CLS row is wanted: q = h[:, :1] Wq^T + bq, kv = h Wkv^T + bkv, with
+    the gradients of the whole in_proj weight and bias assembled in one buffer (slicing the parameter instead costs a
+    zero-fill, a copy and an accumulate per slice in the backward).  h, wb, bb bf16; weight/bias the f32 masters."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, wb, bb):
+        D = h.shape[-1]
+        q = F.linear(h[:, :1], wb[:D], bb[:D])
+        kv = F.linear(h, wb[D:], bb[D:])
+        ctx.save_for_backward(h, wb)
+        return q, kv
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        h, wb = ctx.saved_tensors
+        B, S, D = h.shape
+        dq2, dkv2 = dq.reshape(B, D).contiguous(), dkv.reshape(B * S, 2 * D)
+        dh = (dkv2 @ wb[D:]).view(B, S, D)
+        dh[:, 0] += dq2 @ wb[:D]
+        dw = torch.empty((3 * D, D), dtype=torch.float32, device=h.device)
+        dw[:D] = dq2.t() @ h[:, 0]
+        dw[D:] = _dweight(dkv2, h.view(B * S, D))
+        db = torch.empty(3 * D, dtype=torch.float32, device=h.device)
+        _colsum(dq2, db[:D])
+        _colsum(dkv2, db[D:])
+        return dh, dw, db, None, None
 
 
 def _seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+
+
+_GRAPH_SEED = {}  # device -> int64[1] word the dropout kernels of a captured region mix into their seed
+_capture_site = [0]
+
+
+def graph_seed_state(device) -> torch.Tensor:
+    """The device-resident seed word for hipGraph-captured dropout: whoever replays a captured update advances it
+    (``.add_(1)``, inside or outside the graph) so that every replay draws new masks."""
+    device = torch.device(device)
+    if device not in _GRAPH_SEED:
+        _GRAPH_SEED[device] = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
+    return _GRAPH_SEED[device]
+
+
+def _seed_pair(t: torch.Tensor, p_drop: float):
+    """(seed, seed_state address) for a dropout kernel launch: a fresh host-side seed in eager mode; while a hipGraph is
+    being captured the launch arguments are frozen, so the seed is a per-call-site constant and the randomness comes
+    from ``graph_seed_state`` read by the kernel at run time."""
+    if p_drop <= 0:
+        return 0, 0
+    if torch.cuda.is_current_stream_capturing():
+        _capture_site[0] += 1
+        return (_capture_site[0] * 0x9E3779B97F4A7C15) & (2 ** 62 - 1), graph_seed_state(t.device).data_ptr()
+    return _seed(), 0
 
 
 class _AttnPacked(torch.autograd.Function):
@@ -69,10 +202,10 @@ class _AttnPacked(torch.autograd.Function):
         qkv = qkv.contiguous()
         o = torch.empty((B, S, hw), dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty((B, nhead, S), dtype=torch.float32, device=qkv.device)
-        seed = _seed() if p_drop > 0 else 0
+        seed = _seed_pair(qkv, p_drop)
         base = qkv.data_ptr()
         strides = (S * W, W) * 3
-        nv.attn_fwd(base, base + 2 * hw, base + 4 * hw, o, lse, B, nhead, S, strides, (hw // nhead) ** -0.5, p_drop, seed)
+        nv.attn_fwd(base, base + 2 * hw, base + 4 * hw, o, lse, B, nhead, S, strides, (hw // nhead) ** -0.5, p_drop, *seed)
         ctx.save_for_backward(qkv, lse)
         ctx.meta = (nhead, p_drop, seed)
         return o
@@ -88,7 +221,7 @@ class _AttnPacked(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         base, dbase = qkv.data_ptr(), dqkv.data_ptr()
         nv.attn_bwd(base, base + 2 * hw, base + 4 * hw, do.contiguous(), lse, dbase, dbase + 2 * hw, dbase + 4 * hw, B,
-                    nhead, S, (S * W, W) * 3, (hw // nhead) ** -0.5, p_drop, seed)
+                    nhead, S, (S * W, W) * 3, (hw // nhead) ** -0.5, p_drop, *seed)
         return dqkv, None, None
 
 
@@ -104,10 +237,10 @@ class _AttnCls(torch.autograd.Function):
         q, kv = q.contiguous(), kv.contiguous()
         o = torch.empty((B, 1, hw), dtype=torch.bfloat16, device=kv.device)
         lse = torch.empty((B, nhead, 1), dtype=torch.float32, device=kv.device)
-        seed = _seed() if p_drop > 0 else 0
+        seed = _seed_pair(kv, p_drop)
         kb = kv.data_ptr()
         nv.attn_fwd(q.data_ptr(), kb, kb + 2 * hw, o, lse, B, nhead, 1, (hw, 0, S * W, W, S * W, W),
-                    (hw // nhead) ** -0.5, p_drop, seed)
+                    (hw // nhead) ** -0.5, p_drop, *seed)
         ctx.save_for_backward(q, kv, lse)
         ctx.meta = (nhead, p_drop, seed)
         return o
@@ -123,8 +256,76 @@ class _AttnCls(torch.autograd.Function):
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         kb, db = kv.data_ptr(), dkv.data_ptr()
         nv.attn_bwd(q.data_ptr(), kb, kb + 2 * hw, do.contiguous(), lse, dq.data_ptr(), db, db + 2 * hw, B, nhead, 1,
-                    (hw, 0, S * W, W, S * W, W), (hw // nhead) ** -0.5, p_drop, seed)
+                    (hw, 0, S * W, W, S * W, W), (hw // nhead) ** -0.5, p_drop, *seed)
         return dq, dkv, None, None
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """``x_new = x + dropout(a); h = LayerNorm(x_new).bfloat16()`` in one HIP kernel each way (``g2048_add_ln_fwd/bwd``):
+    the tail of one pre-norm sub-layer fused with the head of the next.  ``a`` None: ``h = LayerNorm(x)`` only.
+    x f32 [..., 256] (a [B, 1, 256] slice of the residual stream is read in place), a bf16; returns (x_new, h)."""
+
+    @staticmethod
+    def forward(ctx, x, a, gamma, beta, eps, p_drop):
+        from ..g2048 import native as nv
+
+        if x.dim() == 3 and x.shape[1] == 1 and x.stride(2) == 1 and x.stride(0) % 4 == 0:
+            row_stride = x.stride(0)
+        else:
+            x, row_stride = x.contiguous(), x.shape[-1]
+        T = x.numel() // 256
+        gamma, beta = gamma.contiguous(), beta.contiguous()
+        h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        stats = torch.empty((2, T), dtype=torch.float32, device=x.device)
+        x_new = None
+        seed = (0, 0)
+        if a is not None:
+            a = a.contiguous()
+            x_new = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            seed = _seed_pair(x, p_drop)
+        nv.add_ln_fwd(x.data_ptr(), row_stride, a, gamma, beta, x_new, h, stats[0], stats[1], T, eps, p_drop, *seed)
+        if a is None:
+            ctx.save_for_backward(x, gamma, stats)
+            ctx.meta = (row_stride, 0.0, (0, 0), False)
+            unused = x.new_empty(0)
+            ctx.mark_non_differentiable(unused)
+            return unused, h
+        ctx.save_for_backward(x_new, gamma, stats)
+        ctx.meta = (256, p_drop, seed, True)
+        return x_new, h
+
+    @staticmethod
+    def backward(ctx, g_x, g_h):
+        from ..g2048 import native as nv
+
+        xn, gamma, stats = ctx.saved_tensors
+        row_stride, p_drop, seed, has_a = ctx.meta
+        T = xn.numel() // 256
+        dx = torch.empty(xn.shape, dtype=torch.float32, device=xn.device)
+        da = torch.empty(xn.shape, dtype=torch.bfloat16, device=xn.device) if has_a else None
+        dgb = torch.zeros((2, 256), dtype=torch.float32, device=xn.device)
+        if g_h is None:
+            g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
+        g_x = g_x.contiguous() if (has_a and g_x is not None) else None
+        nv.add_ln_bwd(xn.data_ptr(), row_stride, g_x, g_h.contiguous(), stats[0], stats[1], gamma, dx, da, dgb[0], dgb[1], T,
+                      p_drop, *seed)
+        return dx, da, dgb[0], dgb[1], None, None
+
+
+def _fused_norm_ok(x: torch.Tensor, a) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and torch.is_grad_enabled()
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and (a is None or a.dtype == torch.bfloat16))
+
+
+def _add_norm(x: torch.Tensor, a, norm: nn.LayerNorm, p: float, training: bool):
+    """(x + dropout(a), LayerNorm(x + dropout(a))); ``a`` None: (x, LayerNorm(x))."""
+    if _fused_norm_ok(x, a):
+        x_new, h = _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, p if training else 0.0)
+        return (x if a is None else x_new), h
+    if a is not None:
+        x = x + F.dropout(a, p, training)
+    return x, F.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)
 
 
 def _fused_attention_ok(t: torch.Tensor, S: int, head_dim: int) -> bool:
@@ -132,10 +333,15 @@ def _fused_attention_ok(t: torch.Tensor, S: int, head_dim: int) -> bool:
             and t.requires_grad)
 
 
-def _linear(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
-    if (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad and torch.is_autocast_enabled()
-            and torch.get_autocast_dtype("cuda") == torch.bfloat16):
-        return _LinearSplitK.apply(x, weight, bias)
+def _train_bf16(t: torch.Tensor, weight: torch.Tensor) -> bool:
+    """The update path: HIP device, gradients wanted, bf16 autocast."""
+    return (t.is_cuda and torch.is_grad_enabled() and weight.requires_grad and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
+def _linear(x: torch.Tensor, weight: torch.Tensor, bias, wb=None, bb=None) -> torch.Tensor:
+    if _train_bf16(x, weight):
+        return _LinearSplitK.apply(x, weight, bias, wb, bb)
     return F.linear(x, weight, bias)
 
 
@@ -188,27 +394,47 @@ class TransformerEncoder(nn.Module):
         self.dim_feedforward, self.dropout = dim_feedforward, dropout
         self.positional_encoding = PositionalEncoding2D(BOARD_DIM[0], BOARD_DIM[1], channels=d_model, dropout=dropout)
         self.cls_token = nn.Parameter(torch.randn(1, 1, d_model))
+        self._shadow = None  # Bf16Shadow of the layers' Linear parameters, built on first use by the update path
         # parameter container with the reference's names; its own forward is not used
         self.encoder = nn.TransformerEncoder(
             nn.TransformerEncoderLayer(d_model=d_model, nhead=nhead, dim_feedforward=dim_feedforward, dropout=dropout,
                                        norm_first=True, batch_first=True),
             num_layers=num_layers, enable_nested_tensor=False)
 
-    def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor, cls_only: bool = False) -> torch.Tensor:
-        """One pre-norm encoder layer.  With ``cls_only`` only the CLS row of the output is produced (keys and
-        values still come from every token): that is all the "cls" reduction reads from the LAST layer, and it
-        skips 16/17 of that layer's query/out-projection/FFN work."""
+    def _bf16_weights(self, like: torch.Tensor):
+        """Per layer [in_proj w, b, out_proj w, b, linear1 w, b, linear2 w, b] as bf16 shadows on the update path
+        (``Bf16Shadow``), else a list of None (``_linear`` then uses the masters directly)."""
+        layers = self.encoder.layers
+        if not _train_bf16(like, layers[0].linear1.weight):
+            return [[None] * 8 for _ in layers]
+        if self._shadow is None:
+            ps = []
+            for l in layers:
+                ps += [l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, l.self_attn.out_proj.weight,
+                       l.self_attn.out_proj.bias, l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias]
+            self._shadow = Bf16Shadow(ps)
+        v = self._shadow()
+        return [v[8 * i:8 * i + 8] for i in range(len(layers))]
+
+    def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor, h: torch.Tensor, next_norm,
+               cls_only: bool = False, sh=(None,) * 8):
+        """One pre-norm encoder layer.  ``h`` = norm1(x), already computed (by the previous layer's tail); returns
+        (x_out, next_norm(x_out)) so that every residual add + dropout + LayerNorm is one fused kernel
+        (``_add_norm``); ``next_norm`` None: (x_out, None).  With ``cls_only`` only the CLS row of the output is
+        produced (keys and values still come from every token): that is all the "cls" reduction reads from the LAST
+        layer, and it skips 16/17 of that layer's query/out-projection/FFN work."""
         B, S, D = x.shape
         H = self.nhead
         p = self.dropout if self.training else 0.0
         attn = layer.self_attn
-        h = F.layer_norm(x, (D,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
         if cls_only:
             w, b = attn.in_proj_weight, attn.in_proj_bias
-            q = _linear(h[:, :1], w[:D], b[:D])
-            kv = _linear(h, w[D:], b[D:])
+            if sh[0] is not None and h.dtype == torch.bfloat16:
+                q, kv = _InProjCls.apply(h, w, b, sh[0], sh[1])
+            else:
+                q = _linear(h[:, :1], w[:D], b[:D])
+                kv = _linear(h, w[D:], b[D:])
             x = x[:, :1]
-            S_out = 1
             if _fused_attention_ok(kv, S, D // H):
                 a = _AttnCls.apply(q, kv, H, p)
             else:
@@ -216,30 +442,34 @@ class TransformerEncoder(nn.Module):
                 a = F.scaled_dot_product_attention(q.view(B, 1, H, D // H).transpose(1, 2), k.transpose(1, 2),
                                                    v.transpose(1, 2), dropout_p=p).transpose(1, 2).reshape(B, 1, D)
         else:
-            qkv = _linear(h, attn.in_proj_weight, attn.in_proj_bias)
-            S_out = S
+            qkv = _linear(h, attn.in_proj_weight, attn.in_proj_bias, sh[0], sh[1])
             if _fused_attention_ok(qkv, S, D // H):
                 a = _AttnPacked.apply(qkv, H, p)
             else:
                 q, k, v = qkv.view(B, S, 3, H, D // H).unbind(dim=2)
                 a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
                                                    dropout_p=p).transpose(1, 2).reshape(B, S, D)
-        a = _linear(a, attn.out_proj.weight, attn.out_proj.bias)
-        x = x + F.dropout(a, p, self.training)
-        h = F.layer_norm(x, (D,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
-        f = F.dropout(F.relu(_linear(h, layer.linear1.weight, layer.linear1.bias)), p, self.training)
-        f = _linear(f, layer.linear2.weight, layer.linear2.bias)
-        return x + F.dropout(f, p, self.training)
+        a = _linear(a, attn.out_proj.weight, attn.out_proj.bias, sh[2], sh[3])
+        x, h = _add_norm(x, a, layer.norm2, p, self.training)
+        f = F.dropout(F.relu(_linear(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5])), p, self.training)
+        f = _linear(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7])
+        if next_norm is None:
+            return x + F.dropout(f, p, self.training), None
+        return _add_norm(x, f, next_norm, p, self.training)
 
     def forward(self, src: torch.Tensor, reduction: str = "mean") -> torch.Tensor:
         """``src`` [B, 16, d_model] token embeddings (no positions yet) -> [B, d_model]."""
         if reduction not in ["mean", "cls"]:
             raise ValueError(f"reduction must be 'mean' or 'cls', got {reduction}")
         x = self.positional_encoding.forward_flat(src)
-        x = torch.cat([self.cls_token.to(x.dtype).expand(x.shape[0], -1, -1), x], dim=1)
-        last = len(self.encoder.layers) - 1
-        for i, layer in enumerate(self.encoder.layers):
-            x = self._layer(layer, x, cls_only=(reduction == "cls" and i == last))
+        x = torch.cat([_ExpandRows.apply(self.cls_token.to(x.dtype), x.shape[0]), x], dim=1)
+        layers = self.encoder.layers
+        last = len(layers) - 1
+        sh = self._bf16_weights(x)
+        x, h = _add_norm(x, None, layers[0].norm1, 0.0, self.training)
+        for i, layer in enumerate(layers):
+            x, h = self._layer(layer, x, h, layers[i + 1].norm1 if i < last else None,
+                               cls_only=(reduction == "cls" and i == last), sh=sh[i])
         if self.encoder.norm is not None:
             x = self.encoder.norm(x)
         return x[:, 0, :] if reduction == "cls" else x[:, 1:, :].mean(dim=1)

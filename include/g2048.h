@@ -154,13 +154,47 @@ int g2048_policy_encoder(const uint8_t *boards, const float *embed_table, const 
  * (reference: nn.TransformerEncoderLayer built at src/ppo/transformer_encoder.py:138-148).
  * q/k/v (and dq/dk/dv) are bf16 with element strides (batch, token) and heads contiguous inside a token, so they may
  * point into the packed in_proj output [B][S][3][H][32] and its gradient; o/dout bf16 [B][Sq][H][32]; lse f32
- * [B][H][Sq].  The dropout mask is a function of (seed, element index): pass the same seed to the backward. */
+ * [B][H][Sq].  The dropout mask is a function of (seed, *seed_state, element index): pass the same pair to the
+ * backward.  seed_state: NULL, or a device-resident 64-bit word read by the kernel at run time, so that a launch
+ * captured in a hipGraph draws a new mask on every replay once the owner advances the word between replays. */
 int g2048_attn_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int64_t B, int H, int Sq,
                    int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, float scale,
-                   float p_drop, uint64_t seed, void *stream);
+                   float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
 int g2048_attn_bwd(const void *q, const void *k, const void *v, const void *dout, const float *lse, void *dq, void *dk,
                    void *dv, int64_t B, int H, int Sq, int64_t q_sb, int64_t q_ss, int64_t k_sb, int64_t k_ss,
-                   int64_t v_sb, int64_t v_ss, float scale, float p_drop, uint64_t seed, void *stream);
+                   int64_t v_sb, int64_t v_ss, float scale, float p_drop, uint64_t seed, const uint64_t *seed_state,
+                   void *stream);
+
+/* ---- policy network (update): residual add + dropout + LayerNorm, d_model 256 ------------------------ */
+
+/* x_new = x + dropout(a);  h = bf16(LayerNorm(x_new) * gamma + beta): the tail of one pre-norm sub-layer fused with
+ * the head of the next (reference: nn.TransformerEncoderLayer(norm_first=True), src/ppo/transformer_encoder.py:138-148;
+ * `x = x + dropout1(sa(norm1(x)))`, `x = x + dropout2(ff(norm2(x)))`).
+ * x f32 rows of 256 with element stride x_row_stride (a strided view of the residual stream is fine); a bf16 [T][256]
+ * or NULL (then x_new is not written and h = LayerNorm(x)); x_new f32 [T][256]; h bf16 [T][256]; mean, rstd f32 [T]
+ * (saved for the backward).  seed, seed_state: as for g2048_attn_fwd; pass the same pair to the backward. */
+int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void *a, const float *gamma, const float *beta,
+                     float *x_new, void *h, float *mean, float *rstd, int64_t T, float eps, float p_drop,
+                     uint64_t seed, const uint64_t *seed_state, void *stream);
+/* x_norm = the tensor that was normalised (x_new, or x when a was NULL); g_x f32 [T][256] or NULL = gradient arriving
+ * on x_new from the residual stream; g_h bf16 [T][256].  dx f32 [T][256] = g_x + dLayerNorm (gradient for x);
+ * da bf16 [T][256] or NULL = dropout-masked dx (gradient for a); dgamma/dbeta f32 [256] are ACCUMULATED into
+ * (float atomics): zero them first. */
+int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
+                     const float *rstd, const float *gamma, float *dx, void *da, float *dgamma, float *dbeta,
+                     int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
+
+/* ---- policy network (update): bias gradients ------------------------------------------------------------ */
+
+/* out[c] = sum_r x[r][c] for x bf16 (is_bf16 != 0) or f32 [T][N] with element stride row_stride between rows; f32
+ * accumulation in a fixed order (bit-reproducible, safe to replay from a hipGraph).  N a multiple of 4, N <= 1024.
+ * The bias gradient of every Linear in the update, and the CLS-token gradient (reference: nn.Linear inside
+ * src/ppo/transformer_encoder.py:138-148 and src/ppo/ppo_agent.py:59-86; PyTorch computes it with at::sum).
+ * workspace: g2048_colsum_workspace_floats(T, N) floats of scratch. */
+#define G2048_COLSUM_MAX_GROUPS 1024
+int g2048_colsum_workspace_floats(int64_t T, int N);
+int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int64_t T, int N, float *workspace, float *out,
+                 void *stream);
 
 #ifdef __cplusplus
 }

@@ -236,3 +236,169 @@ def test_small_attention_kernels_match_sdpa(dev):
     a = _AttnPacked.apply(qkv.clone().requires_grad_(True), H, 0.1)
     b = _AttnPacked.apply(qkv.clone().requires_grad_(True), H, 0.1)
     assert not torch.equal(a, b)  # fresh mask per call
+
+
+def test_fused_add_layernorm_matches_torch(dev):
+    """g2048_add_ln_fwd/bwd vs torch (`x + dropout(a)` then F.layer_norm in f32, cast to bf16): values and all five
+    gradients, contiguous and strided ([B, 1, 256] slice) residual input, ragged row counts; with dropout the kept
+    elements are scaled by 1/(1-p), the mask differs per call and the backward uses the forward's mask."""
+    import torch.nn.functional as F
+
+    from src.ppo.transformer_encoder import _AddLayerNorm
+
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+    torch.manual_seed(1)
+    for shape, sliced in (((3, 17, 256), False), ((1, 1, 256), False), ((2049, 17, 256), False), ((37, 17, 256), True)):
+        base = (torch.randn(shape, device=dev) * 2 + 0.5).requires_grad_(True)
+        x = base[:, :1] if sliced else base
+        a = torch.randn(x.shape, device=dev).to(torch.bfloat16).requires_grad_(True)
+        gamma = (1 + 0.1 * torch.randn(256, device=dev)).requires_grad_(True)
+        beta = (0.1 * torch.randn(256, device=dev)).requires_grad_(True)
+        gx, gh = torch.randn(x.shape, device=dev), torch.randn(x.shape, device=dev).to(torch.bfloat16)
+        for with_a in (True, False):
+            for t in (base, a, gamma, beta):
+                t.grad = None
+            x_new, h = _AddLayerNorm.apply(x, a if with_a else None, gamma, beta, 1e-5, 0.0)
+            if with_a:
+                torch.autograd.backward([x_new, h], [gx, gh])
+            else:
+                h.backward(gh)
+            got = [t.grad.clone() if t.grad is not None else None for t in (base, a, gamma, beta)]
+            for t in (base, a, gamma, beta):
+                t.grad = None
+            xr = x + a.float() if with_a else x
+            hr = F.layer_norm(xr, (256,), gamma, beta, 1e-5)
+            if with_a:
+                torch.autograd.backward([xr, hr], [gx, gh.float()])
+            else:
+                hr.backward(gh.float())
+            if with_a:
+                assert torch.allclose(x_new, xr, atol=1e-6)
+            assert h.dtype == torch.bfloat16 and rel(h, hr) < 3e-3
+            assert rel(got[0], base.grad) < 1e-4, (shape, with_a)
+            if with_a:
+                assert rel(got[1], a.grad) < 4e-3  # bf16 output
+            else:
+                assert got[1] is None
+            assert rel(got[2], gamma.grad) < 1e-4 and rel(got[3], beta.grad) < 1e-4
+    # dropout: x_new - x is either 0 or a/(1-p); the gradient for a is masked the same way
+    x = torch.zeros(4096, 17, 256, device=dev)  # so that x_new - x is exact
+    a = (torch.randn(4096, 17, 256, device=dev).abs() + 0.01).to(torch.bfloat16).requires_grad_(True)
+    gamma, beta = torch.ones(256, device=dev, requires_grad=True), torch.zeros(256, device=dev, requires_grad=True)
+    x_new, h = _AddLayerNorm.apply(x, a, gamma, beta, 1e-5, 0.1)
+    d = x_new - x
+    kept = d != 0
+    assert abs(kept.float().mean().item() - 0.9) < 2e-3
+    assert torch.allclose(d[kept], (a.detach().float() / 0.9)[kept], atol=1e-5, rtol=1e-5)
+    x_new.sum().backward()
+    assert torch.equal(a.grad != 0, kept) and torch.allclose(a.grad[kept].float(), torch.full((1,), 1 / 0.9, device=dev), atol=5e-3)
+    x_new2, _ = _AddLayerNorm.apply(x, a, gamma, beta, 1e-5, 0.1)
+    assert not torch.equal(x_new2, x_new)
+    # every column of a row block keeps ~90 %: no structure along rows or columns
+    assert (kept.float().mean((0, 1)) - 0.9).abs().max() < 0.01 and (kept.float().mean(2) - 0.9).abs().max() < 0.1
+
+
+def test_colsum_matches_torch(dev):
+    """g2048_colsum (bias gradients): f32 column sums of bf16/f32 [T, N], strided rows, ragged T; bit-reproducible."""
+    from src.g2048 import native as nv
+
+    torch.manual_seed(2)
+    for T, N in ((1, 4), (7, 256), (2048, 512), (34816, 768), (34816, 1024), (33000, 256), (5, 1024)):
+        for dt in (torch.bfloat16, torch.float32):
+            x = torch.randn(T, N, device=dev).to(dt)
+            ref = x.double().sum(0)
+            got = nv.colsum(x)
+            assert got.dtype == torch.float32 and got.shape == (N,)
+            assert torch.allclose(got.double(), ref, rtol=2e-5, atol=2e-4 * max(1.0, T ** 0.5))
+            assert torch.equal(got, nv.colsum(x))
+    big = torch.randn(3000, 17, 256, device=dev)
+    assert torch.allclose(nv.colsum(big[:, 0]), big[:, 0].sum(0), rtol=1e-4, atol=1e-3)  # row stride 17*256
+    with pytest.raises(nv.NativeError):
+        nv.colsum(torch.zeros(4, 6, device=dev))  # N not a multiple of 4
+    with pytest.raises(nv.NativeError):
+        nv.colsum(torch.zeros(4, 8))  # host tensor: no CPU path
+
+
+def _ppo_minibatches(tr, dev, n, M):
+    data = tr.rollout_buffer.device_data(dev)
+    ds = PPODataset(data, gamma=tr.gamma, lambda_gae=tr.lambda_gae, max_samples_per_epoch=n * M + M, shuffle_on_reset=False)
+    return list(DeviceBatches(ds, M, drop_last=True).epoch())[:n]
+
+
+def test_hip_graph_update_matches_eager(dev, tmp_path):
+    """The hipGraph-replayed forward+loss+backward gives the eager gradients on batches OTHER than the captured one
+    (dropout off so both are deterministic).  Guards the at::sum-in-a-graph hazard: every bias gradient and the
+    CLS-token gradient must come out of g2048_colsum."""
+    from torch.amp import autocast
+
+    from src.ppo.ppo_trainer import _GraphedFwdBwd
+
+    torch.manual_seed(0)
+    agent = PPOAgent(d_model=256, nhead=8, num_layers=2, dim_feedforward=512, hidden_dim=256, dropout=0.0, reduction="cls")
+    tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), dict(OPTIM), max_steps=1000, device=dev,
+                    rollout_amp=True, log_dir=str(tmp_path), max_samples_per_epoch=100000)
+    assert tr.use_hip_graph  # default for a bf16 update of a graph-safe agent
+    tr.collect_rollouts(512, 1)
+    M = 2048
+    batches = _ppo_minibatches(tr, dev, 3, M)
+    assert len(batches) == 3
+    agent.train()
+    eager = []
+    for b in batches:
+        obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(b)
+        tr._zero_grad()
+        with autocast(device_type="cuda", dtype=torch.bfloat16):
+            loss = tr._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)[0]
+        tr.scaler.scale(loss).backward()
+        eager.append(([p.grad.clone() for p in agent.parameters()], loss.item()))
+    del loss  # a live autograd graph pins the AccumulateGrad nodes to this stream and breaks the capture below
+    obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(batches[0])
+    gr = _GraphedFwdBwd(tr, M, dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret))
+    names = [n for n, _ in agent.named_parameters()]
+    for i in (1, 2, 0, 1):
+        obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(batches[i])
+        stats, _ = gr.run(dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret))
+        assert abs(stats[3].item() - eager[i][1]) < 1e-5
+        for n, p, ge in zip(names, agent.parameters(), eager[i][0]):
+            err = ((p.grad - ge).norm() / ge.norm().clamp_min(1e-20)).item()
+            assert torch.isfinite(p.grad).all() and err < 2e-2, (i, n, err)
+
+
+def test_hip_graph_dropout_draws_new_masks_per_replay(dev):
+    """Dropout launches captured in a hipGraph read graph_seed_state at run time: each replay (after the word moved)
+    draws a new mask, the backward reuses the forward's mask, and call sites inside one graph differ."""
+    from src.ppo.transformer_encoder import _AddLayerNorm, _AttnPacked, graph_seed_state
+
+    torch.manual_seed(3)
+    x = torch.zeros(256, 17, 256, device=dev)
+    a = (torch.rand(256, 17, 256, device=dev) + 0.5).to(torch.bfloat16).requires_grad_(True)
+    qkv = torch.randn(256, 17, 768, device=dev).to(torch.bfloat16).requires_grad_(True)
+    gamma, beta = torch.ones(256, device=dev, requires_grad=True), torch.zeros(256, device=dev, requires_grad=True)
+    word = graph_seed_state(dev)
+
+    def fwd_bwd():
+        x1, _ = _AddLayerNorm.apply(x, a, gamma, beta, 1e-5, 0.25)
+        x2, _ = _AddLayerNorm.apply(x, a, gamma, beta, 1e-5, 0.25)
+        o = _AttnPacked.apply(qkv, 8, 0.25)
+        (da,) = torch.autograd.grad(x1.sum(), a)
+        return x1, x2, o, da
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        word.add_(1)
+        outs = fwd_bwd()
+    seen = []
+    for _ in range(3):
+        g.replay()
+        x1, x2, o, da = [t.clone() for t in outs]
+        assert torch.equal(x1 != 0, da != 0)  # backward mask == forward mask
+        assert not torch.equal(x1 != 0, x2 != 0)  # two call sites, two masks
+        assert abs((x1 != 0).float().mean().item() - 0.75) < 5e-3
+        seen.append((x1, o))
+    assert not torch.equal(seen[0][0], seen[1][0]) and not torch.equal(seen[1][0], seen[2][0])
+    assert not torch.equal(seen[0][1], seen[1][1])

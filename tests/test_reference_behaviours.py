@@ -65,8 +65,10 @@ def test_cls_only_last_layer_equals_full_layer():
     x = torch.randn(5, 16, 64)
     full = enc.positional_encoding.forward_flat(x)
     full = torch.cat([enc.cls_token.expand(5, -1, -1), full], 1)
-    for layer in enc.encoder.layers:
-        full = enc._layer(layer, full, cls_only=False)
+    layers = enc.encoder.layers
+    h = layers[0].norm1(full)
+    for i, layer in enumerate(layers):
+        full, h = enc._layer(layer, full, h, layers[i + 1].norm1 if i + 1 < len(layers) else None, cls_only=False)
     np.testing.assert_allclose(enc(x, reduction="cls").detach().numpy(), full[:, 0].detach().numpy(), atol=1e-5)
     np.testing.assert_allclose(enc(x, reduction="mean").detach().numpy(), full[:, 1:].mean(1).detach().numpy(), atol=1e-5)
     ref = enc.encoder(torch.cat([enc.cls_token.expand(5, -1, -1), enc.positional_encoding.forward_flat(x)], 1))

@@ -1,0 +1,59 @@
+"""Eager vs hipGraph-replayed gradients of one PPO minibatch (dropout off so both are deterministic)."""
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "2048-ppo-agent_amd"))
+sys.path.insert(0, ROOT)
+import torch
+from torch.amp import autocast
+
+import bench
+from src.ppo import PPOAgent, PPOTrainer, RolloutBuffer
+from src.ppo.data_loader import DeviceBatches, PPODataset
+from src.ppo.ppo_trainer import _GraphedFwdBwd
+from src.runs import BatchRunner
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+cfg = dict(bench.MODEL_CFG)
+cfg["dropout"] = 0.0 if "--dropout" not in sys.argv else 0.1
+agent = PPOAgent(**cfg)
+tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), bench.OPTIM_CFG, max_steps=500000, device=dev,
+                rollout_amp=True, log_dir="/tmp/lg", use_hip_graph=True, **bench.TRAINER_CFG)
+tr.collect_rollouts(2048, 1)
+data = tr.rollout_buffer.device_data(dev)
+ds = PPODataset(data, gamma=tr.gamma, lambda_gae=tr.lambda_gae, max_samples_per_epoch=20000, shuffle_on_reset=False)
+batches = list(DeviceBatches(ds, 2048, drop_last=True).epoch())[:4]
+agent.train()
+names = [n for n, _ in agent.named_parameters()]
+
+
+def eager(batch):
+    obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(batch)
+    tr._zero_grad()
+    with autocast(device_type="cuda", dtype=tr.amp_dtype):
+        loss, *_ = tr._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
+    tr.scaler.scale(loss).backward()
+    return [p.grad.clone() for p in agent.parameters()], loss.item()
+
+
+g0 = [eager(b) for b in batches]
+obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(batches[0])
+sample = dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret)
+gr = _GraphedFwdBwd(tr, 2048, sample)
+for rep in range(2):
+    for i, b in enumerate(batches):
+        obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(b)
+        stats, kl = gr.run(dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret))
+        torch.cuda.synchronize()
+        worst = []
+        for n, p, ge in zip(names, agent.parameters(), g0[i][0]):
+            g = p.grad
+            if not torch.isfinite(g).all():
+                worst.append((n, "NONFINITE", int((~torch.isfinite(g)).sum())))
+            else:
+                r = ((g - ge).norm() / ge.norm().clamp_min(1e-20)).item()
+                if r > 2e-2:
+                    worst.append((n, round(r, 4)))
+        print(f"rep {rep} batch {i}: loss graph {stats[3].item():.6f} eager {g0[i][1]:.6f}; {len(worst)} bad params", worst[:8], flush=True)

@@ -1,22 +1,54 @@
-import sys, os, time
+"""Where does one PPO minibatch go?  wall ms/minibatch (eager and hipGraph), GPU-busy ms, kernels per minibatch,
+and the kernel table by time and by launch count.  usage: python tools/probe_update.py [rows]"""
+import os
+import sys
+import time
+
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(ROOT, "2048-ppo-agent_amd")); sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "2048-ppo-agent_amd"))
+sys.path.insert(0, ROOT)
 import torch
+
 import bench
 from src.ppo import PPOAgent, PPOTrainer, RolloutBuffer
 from src.runs import BatchRunner
-dev = torch.device("cuda:0"); torch.manual_seed(0)
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
 agent = PPOAgent(**bench.MODEL_CFG)
-tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31,16,4), bench.OPTIM_CFG, max_steps=500000, device=dev, rollout_amp=True, log_dir="/tmp/lg", **bench.TRAINER_CFG)
+tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), bench.OPTIM_CFG, max_steps=500000, device=dev,
+                rollout_amp=True, log_dir="/tmp/lg", **bench.TRAINER_CFG)
 tr.collect_rollouts(8192, 1)
 tr.max_samples_per_epoch = 40000
+
+
 def upd():
-    torch.cuda.synchronize(); t=time.time(); m=tr.update_policy(batch_size=2048, n_epochs=2); torch.cuda.synchronize(); return (time.time()-t)/max(m["n_updates"],1)*1e3, m["n_updates"]
-print("warm", upd()); print("graph ms/minibatch", upd())
-tr.use_hip_graph=False
-print("eager ms/minibatch", upd())
-tr.use_hip_graph=True
-from torch.profiler import profile, ProfilerActivity
+    torch.cuda.synchronize()
+    t = time.time()
+    m = tr.update_policy(batch_size=2048, n_epochs=2)
+    t_cpu = time.time() - t
+    torch.cuda.synchronize()
+    n = max(m["n_updates"], 1)
+    return round((time.time() - t) / n * 1e3, 3), round(t_cpu / n * 1e3, 3), n
+
+
+print("warm", upd())
+print("eager (wall ms/minibatch, host-side ms/minibatch, minibatches)", upd())
+if "--graph" in sys.argv:
+    tr.use_hip_graph = True
+    print("graph warm", upd())
+    print("graph", upd())
+    tr.use_hip_graph = False
+from torch.profiler import ProfilerActivity, profile
+
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
-    upd()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=70))
+    _, _, n = upd()
+ka = prof.key_averages()
+tot = sum(k.self_device_time_total for k in ka)
+cnt = sum(k.count for k in ka)
+print(f"GPU busy {tot / n / 1e3:.3f} ms/minibatch in {cnt / n:.0f} kernels/minibatch")
+print(ka.table(sort_by="cuda_time_total", row_limit=rows, max_name_column_width=90))
+print("by launch count:")
+for k in sorted(ka, key=lambda k: -k.count)[:rows]:
+    print(f"{k.count / n:7.1f}/mb {k.self_device_time_total / n:9.1f} us/mb  {k.key[:150]}")
