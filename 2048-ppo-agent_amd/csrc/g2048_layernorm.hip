@@ -207,20 +207,21 @@ k_colsum_partial(const void *__restrict__ x, int64_t rs, int64_t T, int N, float
     }
 }
 
-__global__ void __launch_bounds__(256)
+// 64 columns per workgroup, 16 interleaved slices of the G partial rows per column, combined through LDS in a fixed order
+__global__ void __launch_bounds__(1024)
 k_colsum_final(const float *__restrict__ partial, int G, int N, float *__restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = 0;
-    for (; g + 4 <= G; g += 4) {
-        s0 += partial[(int64_t)g * N + c];
-        s1 += partial[(int64_t)(g + 1) * N + c];
-        s2 += partial[(int64_t)(g + 2) * N + c];
-        s3 += partial[(int64_t)(g + 3) * N + c];
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < N)
+        for (int g = slice; g < G; g += 16) s += partial[(int64_t)g * N + c];
+    red[slice][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (slice == 0 && c < N) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        out[c] = t;
     }
-    for (; g < G; ++g) s0 += partial[(int64_t)g * N + c];
-    out[c] = (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace
@@ -237,8 +238,8 @@ extern "C" int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int6
         return G2048_EINVAL;
     const int rows_per_pass = CS_THREADS / (N / CS_VEC);
     int64_t G = (T + rows_per_pass - 1) / rows_per_pass;
-    // at least ~32 rows per workgroup, at most MAX_GROUPS workgroups
-    G = (G + 31) / 32;
+    // at least ~16 rows per workgroup, at most MAX_GROUPS workgroups
+    G = (G + 15) / 16;
     if (G > G2048_COLSUM_MAX_GROUPS) G = G2048_COLSUM_MAX_GROUPS;
     if (G < 1) G = 1;
     if (is_bf16)
@@ -247,7 +248,7 @@ extern "C" int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int6
     else
         hipLaunchKernelGGL(k_colsum_partial<false>, dim3((unsigned)G), dim3(CS_THREADS), 0, (hipStream_t)stream, x, row_stride, T, N,
                            workspace);
-    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, (int)G, N,
+    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, workspace, (int)G, N,
                        out);
     return done();
 }

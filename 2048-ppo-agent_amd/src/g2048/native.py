@@ -47,6 +47,8 @@ SIGNATURES = {
     "g2048_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,
                        C.c_float, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_add_ln_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_ppo_loss": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp,
+                       _vp, _vp],
     "g2048_colsum_workspace_floats": [_i64, _i32],
     "g2048_colsum": [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp],
     "g2048_add_ln_bwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp,
@@ -294,7 +296,7 @@ def add_ln_bwd(xn_ptr: int, x_row_stride: int, g_x, g_h, mean, rstd, gamma, dx, 
            "g2048_add_ln_bwd")
 
 
-COLSUM_MAX_GROUPS = 1024
+COLSUM_MAX_GROUPS = 512
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -309,3 +311,22 @@ def colsum(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     _check(load().g2048_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), x.stride(0), T, N, ws.data_ptr(),
                                _dev(out, f32, N, "out"), _stream()), "g2048_colsum")
     return out
+
+
+def ppo_loss(logits, values, actions, mask_bits, old_logp, adv, ret, clip_eps: float, c_value: float, c_entropy: float):
+    """-> (new_logp f32 [M], sums f32 [5], dlogits like logits, dvalues like values); see g2048_ppo_loss."""
+    M = actions.numel()
+    for name, t in (("logits", logits), ("values", values)):
+        if not t.is_cuda or t.dtype not in (torch.bfloat16, f32) or not t.is_contiguous():
+            raise NativeError(f"{name}: expected a contiguous bf16/f32 device tensor, got {t.dtype} on {t.device}")
+    if logits.numel() != 4 * M or values.numel() != M:
+        raise NativeError(f"ppo_loss: logits {tuple(logits.shape)} / values {tuple(values.shape)} do not match M={M}")
+    new_logp = torch.empty(M, dtype=f32, device=logits.device)
+    sums = torch.empty(5, dtype=f32, device=logits.device)
+    dlogits, dvalues = torch.empty_like(logits), torch.empty_like(values)
+    _check(load().g2048_ppo_loss(
+        logits.data_ptr(), int(logits.dtype == torch.bfloat16), values.data_ptr(), int(values.dtype == torch.bfloat16),
+        _dev(actions, u8, M, "actions"), _dev(mask_bits, u8, M, "mask_bits", optional=True), _dev(old_logp, f32, M, "old_logp"),
+        _dev(adv, f32, M, "adv"), _dev(ret, f32, M, "ret"), M, float(clip_eps), float(c_value), float(c_entropy),
+        new_logp.data_ptr(), sums.data_ptr(), dlogits.data_ptr(), dvalues.data_ptr(), _stream()), "g2048_ppo_loss")
+    return new_logp, sums, dlogits, dvalues

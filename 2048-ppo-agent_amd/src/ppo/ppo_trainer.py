@@ -10,6 +10,7 @@ test are reduced globally so every rank takes the same decisions.
 """
 from __future__ import annotations
 
+import contextlib
 import logging
 from collections import deque
 from typing import Dict, Literal, Optional
@@ -68,6 +69,29 @@ def _tail(seq, k: int):
     return items[-k:] if k > 0 else []
 
 
+class _FusedPPOLoss(torch.autograd.Function):
+    """``_compute_ppo_loss`` in one HIP launch (``g2048_ppo_loss``): forward, the logged means and the gradient.
+
+    -> (sums f32 [5] = mean policy, value, entropy, TOTAL loss, mean(old - new log-prob); new_log_probs [M]).
+    Only ``sums[3]`` is differentiable: backward scales the gradients the kernel already produced."""
+
+    @staticmethod
+    def forward(ctx, logits, values, actions_u8, mask_bits, old_lp, adv, ret, clip_eps, c_value, c_entropy):
+        from ..g2048 import native as nv
+
+        new_lp, sums, dlogits, dvalues = nv.ppo_loss(logits.contiguous(), values.contiguous(), actions_u8, mask_bits, old_lp,
+                                                     adv, ret, clip_eps, c_value, c_entropy)
+        ctx.save_for_backward(dlogits, dvalues)
+        ctx.mark_non_differentiable(new_lp)
+        return sums, new_lp
+
+    @staticmethod
+    def backward(ctx, g_sums, _g_new_lp):
+        dlogits, dvalues = ctx.saved_tensors
+        g = g_sums[3]
+        return dlogits * g, dvalues * g, None, None, None, None, None, None, None, None
+
+
 class _GraphedFwdBwd:
     """One minibatch of ``_compute_ppo_loss`` + (scaled) backward captured in a hipGraph.
 
@@ -110,21 +134,10 @@ class _GraphedFwdBwd:
         self.tr._zero_grad()
 
     def _fwd_bwd(self):
-        tr, st = self.tr, self.static
-        args = (st["obs"], st["actions"], st["masks"], st["old_lp"], st["adv"], st["ret"])
-        if tr.use_amp:
-            # autocast's weight-cast cache must be off inside a captured region (PyTorch CUDA-graphs + AMP rule):
-            # with it on, the replayed graph produced non-finite bias gradients
-            with autocast(device_type="cuda", dtype=tr.amp_dtype, cache_enabled=False):
-                loss, pl, vl, el, new_lp = tr._compute_ppo_loss(*args)
-            tr.scaler.scale(loss).backward()
-        else:
-            loss, pl, vl, el, new_lp = tr._compute_ppo_loss(*args)
-            loss.backward()
-        with torch.no_grad():
-            stats = torch.stack([pl.mean(), vl.mean(), el.mean(), loss.detach()]).double()
-            kl = (st["old_lp"] - new_lp).mean().double()
-        return stats, kl
+        st = self.static
+        # autocast's weight-cast cache must be off inside a captured region (PyTorch CUDA-graphs + AMP rule)
+        return self.tr._loss_backward(st["obs"], st["actions"], st["masks"], st["old_lp"], st["adv"], st["ret"],
+                                      cache_enabled=False, zero=False)
 
     def run(self, batch: dict):
         for k, v in batch.items():
@@ -319,35 +332,68 @@ class PPOTrainer:
         loss = (policy_loss + self.value_loss_coef * value_loss + self.entropy_coef * entropy_loss).mean()
         return loss, policy_loss, value_loss, entropy_loss, new_log_probs
 
-    def _eager_fwd_bwd(self, obs, actions, masks, old_lp, adv, ret):
-        """Forward + loss + (scaled) backward of one minibatch -> (stats [4] f64, kl [1] f64), both detached.  Nothing
-        that references the autograd graph leaves this frame: a live graph keeps the parameters' AccumulateGrad nodes
-        (and the stream they were created on) alive, and a later hipGraph capture on another stream would then have
-        to synchronise with that stream, which breaks the capture."""
-        if self.use_amp:
-            with autocast(device_type="cuda", dtype=self.amp_dtype):
+    def _fused_loss_ok(self) -> bool:
+        return self.device.type == "cuda" and getattr(self.agent, "action_dim", 4) == 4
+
+    def _loss_backward(self, obs, actions, masks, old_lp, adv, ret, cache_enabled: bool = True, zero: bool = True):
+        """Forward + loss + (scaled) backward of one minibatch -> (stats [4] f64: mean policy, value, entropy, total
+        loss; kl [1] f64), both detached.  On the device the loss, its means and its gradient are one HIP launch
+        (``_FusedPPOLoss``; actions/masks arrive packed, see ``_unpack_batch``), else ``_compute_ppo_loss``.
+        Nothing that references the autograd graph leaves this frame: a live graph keeps the parameters'
+        AccumulateGrad nodes (and the stream they were created on) alive, and a later hipGraph capture on another
+        stream would then have to synchronise with that stream, which breaks the capture."""
+        fused = self._fused_loss_ok()
+        ctx = autocast(device_type="cuda", dtype=self.amp_dtype, cache_enabled=cache_enabled) if self.use_amp \
+            else contextlib.nullcontext()
+        with ctx:
+            if fused:
+                logits, values = self.agent(obs, None)
+                sums, new_lp = _FusedPPOLoss.apply(logits, values.reshape(-1), actions,
+                                                   masks if self.use_action_mask else None, old_lp, adv, ret,
+                                                   self.clip_epsilon, self.value_loss_coef, self.entropy_coef)
+            else:
                 loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
-        else:
-            loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
-        self._zero_grad()
+        if zero:
+            self._zero_grad()
+        if fused:
+            out = self.scaler.scale(sums) if self.use_amp else sums
+            out.backward(self._loss_selector())
+            with torch.no_grad():
+                d = sums.detach().double()
+                return d[:4], d[4:5]
         if self.use_amp:
             self.scaler.scale(loss).backward()
         else:
             loss.backward()
         with torch.no_grad():
             stats = torch.stack([pl.mean(), vl.mean(), el.mean(), loss.detach()]).double()
-            kl = (old_lp - new_lp).mean().double()
+            kl = (old_lp - new_lp).mean().double().reshape(1)
         return stats, kl
 
-    def _unpack_batch(self, batch):
+    def _loss_selector(self) -> torch.Tensor:
+        """d(total)/d(sums): picks the total loss out of the fused loss kernel's five means."""
+        if getattr(self, "_sel", None) is None or self._sel.device != self.device:
+            self._sel = torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0], device=self.device)
+        return self._sel
+
+    def _unpack_batch(self, batch, packed: bool = False):
+        """-> (obs, actions, masks, old_log_probs, advantages, returns).  ``packed`` (the fused loss kernel's layout):
+        actions u8 [M] and masks u8 [M] bitmasks, else actions int64 [M] and masks bool [M, 4]."""
         obs = batch["observations"]
         actions = batch["actions"]
         masks = batch["action_masks"]
         if actions.dim() > 1:  # reference layout: one-hot float actions
             actions = actions.argmax(dim=-1)
-        actions = actions.long()
-        if masks.dtype == torch.uint8 and masks.dim() == 1:  # packed bitmask -> [M, 4]
-            masks = (masks.unsqueeze(-1) & torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=masks.device)) != 0
+        if packed:
+            actions = actions.to(torch.uint8)
+            if masks.dim() > 1:
+                bits = torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=masks.device)
+                masks = (masks.to(torch.uint8) * bits).sum(-1).to(torch.uint8)
+        else:
+            actions = actions.long()
+            if masks.dtype == torch.uint8 and masks.dim() == 1:  # packed bitmask -> [M, 4]
+                bits = torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=masks.device)
+                masks = (masks.unsqueeze(-1) & bits) != 0
         return obs, actions, masks, batch["log_probs"], batch["advantages"], batch["returns"]
 
     # ------------------------------------------------------------------ update
@@ -377,7 +423,7 @@ class PPOTrainer:
             for batch in batches.epoch():
                 if done_batches >= n_per_epoch:
                     break
-                obs, actions, masks, old_lp, adv, ret = self._unpack_batch(batch)
+                obs, actions, masks, old_lp, adv, ret = self._unpack_batch(batch, packed=self._fused_loss_ok())
                 graphed = None
                 if self.use_hip_graph and obs.shape[0] == batch_size:
                     sample = dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret)
@@ -387,7 +433,7 @@ class PPOTrainer:
                     graphed = self._graphs[gkey]
                     stats, kl = graphed.run(sample)
                 else:
-                    stats, kl = self._eager_fwd_bwd(obs, actions, masks, old_lp, adv, ret)
+                    stats, kl = self._loss_backward(obs, actions, masks, old_lp, adv, ret)
                 self._allreduce_grads()
                 if self.use_amp:
                     self.scaler.unscale_(self.optimizer)

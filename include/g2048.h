@@ -191,10 +191,25 @@ int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x
  * The bias gradient of every Linear in the update, and the CLS-token gradient (reference: nn.Linear inside
  * src/ppo/transformer_encoder.py:138-148 and src/ppo/ppo_agent.py:59-86; PyTorch computes it with at::sum).
  * workspace: g2048_colsum_workspace_floats(T, N) floats of scratch. */
-#define G2048_COLSUM_MAX_GROUPS 1024
+#define G2048_COLSUM_MAX_GROUPS 512
 int g2048_colsum_workspace_floats(int64_t T, int N);
 int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int64_t T, int N, float *workspace, float *out,
                  void *stream);
+
+/* ---- PPO update: loss ------------------------------------------------------------------------------------- */
+
+/* Clipped-surrogate PPO loss of one minibatch, forward + gradient in one launch (reference:
+ * PPOTrainer._compute_ppo_loss src/ppo/ppo_trainer.py:251-314 over PPOAgent.evaluate_actions src/ppo/ppo_agent.py:159-191).
+ * logits [M][4] and values [M]: f32, or bf16 when the *_bf16 flag is set; actions u8 [M] (0..3); mask_bits u8 [M]
+ * (bit a = action a legal) or NULL for no masking; old_logp, adv, ret f32 [M].
+ * Out: new_logp f32 [M]; sums f32 [5] = mean policy loss, mean value loss, mean entropy loss (-H), mean total loss,
+ * mean(old_logp - new_logp); dlogits [M][4] and dvalues [M] = d(mean total loss)/d(input) in the input's dtype.
+ * total = policy + c_value * value + c_entropy * entropy_loss.  One workgroup, fixed summation order. */
+#define G2048_PPO_LOSS_MAX_BATCH 1048576
+int g2048_ppo_loss(const void *logits, int logits_bf16, const void *values, int values_bf16, const uint8_t *actions,
+                   const uint8_t *mask_bits, const float *old_logp, const float *adv, const float *ret, int64_t M,
+                   float clip_eps, float c_value, float c_entropy, float *new_logp, float *sums, void *dlogits,
+                   void *dvalues, void *stream);
 
 #ifdef __cplusplus
 }

@@ -329,8 +329,6 @@ def test_hip_graph_update_matches_eager(dev, tmp_path):
     """The hipGraph-replayed forward+loss+backward gives the eager gradients on batches OTHER than the captured one
     (dropout off so both are deterministic).  Guards the at::sum-in-a-graph hazard: every bias gradient and the
     CLS-token gradient must come out of g2048_colsum."""
-    from torch.amp import autocast
-
     from src.ppo.ppo_trainer import _GraphedFwdBwd
 
     torch.manual_seed(0)
@@ -345,23 +343,19 @@ def test_hip_graph_update_matches_eager(dev, tmp_path):
     agent.train()
     eager = []
     for b in batches:
-        obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(b)
-        tr._zero_grad()
-        with autocast(device_type="cuda", dtype=torch.bfloat16):
-            loss = tr._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)[0]
-        tr.scaler.scale(loss).backward()
-        eager.append(([p.grad.clone() for p in agent.parameters()], loss.item()))
-    del loss  # a live autograd graph pins the AccumulateGrad nodes to this stream and breaks the capture below
-    obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(batches[0])
+        stats, _ = tr._loss_backward(*tr._unpack_batch(b, packed=True))  # the same code path, launched eagerly
+        eager.append(([p.grad.clone() for p in agent.parameters()], stats[3].item()))
+    obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(batches[0], packed=True)
     gr = _GraphedFwdBwd(tr, M, dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret))
     names = [n for n, _ in agent.named_parameters()]
     for i in (1, 2, 0, 1):
-        obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(batches[i])
+        obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(batches[i], packed=True)
         stats, _ = gr.run(dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret))
-        assert abs(stats[3].item() - eager[i][1]) < 1e-5
+        assert abs(stats[3].item() - eager[i][1]) < 1e-6
         for n, p, ge in zip(names, agent.parameters(), eager[i][0]):
             err = ((p.grad - ge).norm() / ge.norm().clamp_min(1e-20)).item()
-            assert torch.isfinite(p.grad).all() and err < 2e-2, (i, n, err)
+            # same kernels either way; only the float atomics of the LayerNorm weight gradients reorder
+            assert torch.isfinite(p.grad).all() and err < 1e-3, (i, n, err)
 
 
 def test_hip_graph_dropout_draws_new_masks_per_replay(dev):
@@ -402,3 +396,49 @@ def test_hip_graph_dropout_draws_new_masks_per_replay(dev):
         seen.append((x1, o))
     assert not torch.equal(seen[0][0], seen[1][0]) and not torch.equal(seen[1][0], seen[2][0])
     assert not torch.equal(seen[0][1], seen[1][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("use_mask", [True, False])
+def test_fused_ppo_loss_matches_torch(dev, dtype, use_mask):
+    """g2048_ppo_loss vs the torch restatement of the reference loss (PPOTrainer._compute_ppo_loss): per-sample
+    log-probs, the five means and the gradients for logits and values; ratios inside, outside and next to the ends of the clip
+    interval, zero advantages (torch.min ties), masked actions, ragged M."""
+    from src.g2048 import native as nv
+
+    torch.manual_seed(5)
+    for M in (1, 7, 2048, 5000):
+        logits = (torch.randn(M, 4, device=dev) * 2).to(dtype)
+        values = torch.randn(M, device=dev).to(dtype)
+        bits = torch.randint(1, 16, (M,), device=dev, dtype=torch.uint8)
+        mask = (bits.unsqueeze(-1) & torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=dev)) != 0
+        actions = torch.multinomial(mask.float(), 1).squeeze(1)  # always a legal action
+        adv, ret = torch.randn(M, device=dev), torch.randn(M, device=dev)
+        adv[::5] = 0.0
+        l32 = logits.float().requires_grad_(True)
+        v32 = values.float().requires_grad_(True)
+        z = l32 - 1e8 * (1 - mask.float()) if use_mask else l32
+        d = torch.distributions.Categorical(logits=z, validate_args=False)
+        new_lp = d.log_prob(actions)
+        old_lp = (new_lp.detach() + 0.3 * torch.randn(M, device=dev)).contiguous()
+        old_lp[1::7] = new_lp.detach()[1::7]  # ratio == 1: inside the clip range, surr1 == surr2
+        old_lp[2::11] = new_lp.detach()[2::11] - float(np.log(1.2 * 1.001))  # ratio just outside the clip range
+        old_lp[3::11] = new_lp.detach()[3::11] - float(np.log(1.2 * 0.999))  # ... and just inside
+        ratio = torch.exp(new_lp - old_lp)
+        pl = -torch.min(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv)
+        vl = (v32 - ret) ** 2
+        el = -d.entropy()
+        total = (pl + 0.5 * vl + 0.01 * el).mean()
+        total.backward()
+        got_lp, sums, dl, dv = nv.ppo_loss(logits, values, actions.to(torch.uint8), bits if use_mask else None, old_lp, adv, ret,
+                                           0.2, 0.5, 0.01)
+        tol = dict(rtol=2e-4, atol=2e-5)
+        assert torch.allclose(got_lp, new_lp.detach(), **tol)
+        want = torch.stack([pl.mean(), vl.mean(), el.mean(), total, (old_lp - new_lp).mean()]).detach()
+        assert torch.allclose(sums, want, rtol=2e-4, atol=2e-5), (M, sums, want)
+        assert dl.dtype == dtype and dv.dtype == dtype and dl.shape == logits.shape
+        gtol = dict(rtol=2e-2, atol=2e-6) if dtype == torch.bfloat16 else dict(rtol=5e-4, atol=1e-8)
+        assert torch.allclose(dl.float(), l32.grad, **gtol), (M, (dl.float() - l32.grad).abs().max())
+        assert torch.allclose(dv.float(), v32.grad, **gtol)
+        assert torch.equal(sums, nv.ppo_loss(logits, values, actions.to(torch.uint8), bits if use_mask else None, old_lp, adv,
+                                             ret, 0.2, 0.5, 0.01)[1])  # fixed summation order

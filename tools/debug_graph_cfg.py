@@ -24,7 +24,7 @@ data = tr.rollout_buffer.device_data(dev)
 ds = PPODataset(data, gamma=tr.gamma, lambda_gae=tr.lambda_gae, max_samples_per_epoch=20000, shuffle_on_reset=False)
 b = list(DeviceBatches(ds, 2048, drop_last=True).epoch())[0]
 agent.train()
-obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(b)
+obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(b, packed=True)
 print("capturing", sys.argv[1:], flush=True)
 gr = _GraphedFwdBwd(tr, 2048, dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret))
 gr.run(dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret))

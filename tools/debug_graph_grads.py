@@ -39,12 +39,12 @@ def eager(batch):
 
 
 g0 = [eager(b) for b in batches]
-obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(batches[0])
+obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(batches[0], packed=True)
 sample = dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret)
 gr = _GraphedFwdBwd(tr, 2048, sample)
 for rep in range(2):
     for i, b in enumerate(batches):
-        obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(b)
+        obs, actions, masks, old_lp, adv, ret = tr._unpack_batch(b, packed=True)
         stats, kl = gr.run(dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret))
         torch.cuda.synchronize()
         worst = []

@@ -33,13 +33,13 @@ def upd():
     return round((time.time() - t) / n * 1e3, 3), round(t_cpu / n * 1e3, 3), n
 
 
+print("hipGraph update:", tr.use_hip_graph)
 print("warm", upd())
-print("eager (wall ms/minibatch, host-side ms/minibatch, minibatches)", upd())
-if "--graph" in sys.argv:
-    tr.use_hip_graph = True
-    print("graph warm", upd())
-    print("graph", upd())
+print("graph (wall ms/minibatch, host-side ms/minibatch, minibatches)", upd())
+if "--eager" in sys.argv:
     tr.use_hip_graph = False
+    print("eager warm", upd())
+    print("eager", upd())
 from torch.profiler import ProfilerActivity, profile
 
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
