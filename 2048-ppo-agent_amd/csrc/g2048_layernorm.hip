@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int D = 256, ROWS_PER_BLOCK = 32, WAVES = 4;
+constexpr int D = 256, ROWS_PER_BLOCK = 64, WAVES = 4;
 
 __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -78,16 +78,18 @@ k_add_ln_fwd(const float *__restrict__ x, int64_t x_rs, const uint16_t *__restri
 // xn: the tensor that was normalised (x_new, or x itself when there was no branch), row stride xn_rs.
 // g_x: gradient flowing into x_new from the residual stream (f32 [T][256], may be null); g_h: bf16 [T][256].
 // dx (f32 [T][256]) = g_x + dLN;  da (bf16 [T][256], may be null) = dropout-masked dx.
+// partial[blockIdx][3][256]: this workgroup's column sums of g_h * xhat (-> dgamma), g_h (-> dbeta) and the bf16 values
+// written to da (-> the bias gradient of the Linear that produced a); summed over workgroups by k_colsum_final.
 __global__ void __launch_bounds__(64 * WAVES)
 k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restrict__ g_x, const uint16_t *__restrict__ g_h,
              const float *__restrict__ mean_in, const float *__restrict__ rstd_in, const float *__restrict__ gamma,
-             float *__restrict__ dx, uint16_t *__restrict__ da, float *__restrict__ dgamma, float *__restrict__ dbeta,
+             float *__restrict__ dx, uint16_t *__restrict__ da, float *__restrict__ partial,
              int64_t T, float inv_keep, uint32_t thr, uint32_t s0, uint32_t s1, const uint64_t *seed_state) {
     mix_seed_state(seed_state, s0, s1);
-    __shared__ float red[WAVES][2][D];
+    __shared__ float red[WAVES][3][D];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float4 g = reinterpret_cast<const float4 *>(gamma)[lane];
-    float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+    float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0}, dsum[4] = {0, 0, 0, 0};
     const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
     for (int r = w; r < ROWS_PER_BLOCK; r += WAVES) {
         const int64_t row = row0 + r;
@@ -117,19 +119,25 @@ k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restric
                 const uint64_t base = (uint64_t)row * D + 4 * lane;
                 for (int q = 0; q < 4; ++q) o[q] = keep_elem(s0, s1, thr, base + q) ? o[q] * inv_keep : 0.0f;
             }
-            reinterpret_cast<uint2 *>(da + row * D)[lane] = make_uint2(f2bf(o[0]) | (f2bf(o[1]) << 16), f2bf(o[2]) | (f2bf(o[3]) << 16));
+            uint32_t b[4];
+            for (int q = 0; q < 4; ++q) {
+                b[q] = f2bf(o[q]);
+                dsum[q] += bf2f(b[q]);  // what at::sum over the bf16 tensor would add
+            }
+            reinterpret_cast<uint2 *>(da + row * D)[lane] = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
         }
     }
     for (int q = 0; q < 4; ++q) {
         red[w][0][4 * lane + q] = dg[q];
         red[w][1][4 * lane + q] = db[q];
+        red[w][2][4 * lane + q] = dsum[q];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * D; c += 64 * WAVES) {
+    for (int c = threadIdx.x; c < 3 * D; c += 64 * WAVES) {
         const int which = c / D, col = c - which * D;
         float s = 0.f;
         for (int ww = 0; ww < WAVES; ++ww) s += red[ww][which][col];
-        atomicAdd((which ? dbeta : dgamma) + col, s);
+        partial[(int64_t)blockIdx.x * 3 * D + c] = s;
     }
 }
 
@@ -152,21 +160,6 @@ extern "C" int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void
     hipLaunchKernelGGL(k_add_ln_fwd, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(64 * WAVES), 0, (hipStream_t)stream, x,
                        x_row_stride, (const uint16_t *)a, gamma, beta, x_new, (uint16_t *)h, mean, rstd, T, eps,
                        1.0f / (1.0f - p_drop), thr, (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
-    return done();
-}
-
-extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
-                                const float *rstd, const float *gamma, float *dx, void *da, float *dgamma, float *dbeta,
-                                int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream) {
-    if (!x_norm || !g_h || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || T <= 0 || (x_row_stride & 3) ||
-        !(p_drop >= 0.f && p_drop < 1.f) || (((uintptr_t)x_norm | (uintptr_t)g_x | (uintptr_t)dx | (uintptr_t)gamma) & 15) ||
-        (((uintptr_t)g_h | (uintptr_t)da) & 7))
-        return G2048_EINVAL;
-    const uint32_t thr = da ? (uint32_t)(p_drop * 16777216.0f) : 0u;
-    const int64_t blocks = (T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(k_add_ln_bwd, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream, x_norm, x_row_stride, g_x,
-                       (const uint16_t *)g_h, mean, rstd, gamma, dx, (uint16_t *)da, dgamma, dbeta, T, 1.0f / (1.0f - p_drop),
-                       thr, (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
     return done();
 }
 
@@ -226,9 +219,9 @@ k_colsum_final(const float *__restrict__ partial, int G, int N, float *__restric
 
 }  // namespace
 
-extern "C" int g2048_colsum_workspace_floats(int64_t T, int N) {
-    if (T <= 0 || N <= 0) return G2048_EINVAL;
-    return G2048_COLSUM_MAX_GROUPS * N;
+extern "C" int64_t g2048_colsum_workspace_floats(int64_t T, int N) {
+    if (T <= 0 || N <= 0) return 0;
+    return (int64_t)G2048_COLSUM_MAX_GROUPS * N;
 }
 
 extern "C" int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int64_t T, int N, float *workspace, float *out,
@@ -250,5 +243,125 @@ extern "C" int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int6
                            workspace);
     hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, workspace, (int)G, N,
                        out);
+    return done();
+}
+
+extern "C" int64_t g2048_add_ln_bwd_workspace_floats(int64_t T) {
+    return T <= 0 ? 0 : ((T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * 3 * D;
+}
+
+extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
+                                const float *rstd, const float *gamma, float *dx, void *da, float *dparams, float *workspace,
+                                int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream) {
+    if (!x_norm || !g_h || !mean || !rstd || !gamma || !dx || !dparams || !workspace || T <= 0 || (x_row_stride & 3) ||
+        !(p_drop >= 0.f && p_drop < 1.f) || (((uintptr_t)x_norm | (uintptr_t)g_x | (uintptr_t)dx | (uintptr_t)gamma) & 15) ||
+        (((uintptr_t)g_h | (uintptr_t)da) & 7))
+        return G2048_EINVAL;
+    const uint32_t thr = da ? (uint32_t)(p_drop * 16777216.0f) : 0u;
+    const int64_t blocks = (T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(k_add_ln_bwd, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream, x_norm, x_row_stride, g_x,
+                       (const uint16_t *)g_h, mean, rstd, gamma, dx, (uint16_t *)da, workspace, T, 1.0f / (1.0f - p_drop), thr,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
+    hipLaunchKernelGGL(k_colsum_final, dim3(3 * D / 64), dim3(1024), 0, (hipStream_t)stream, workspace, (int)blocks, 3 * D, dparams);
+    return done();
+}
+
+// ---- feed-forward activation: y = dropout(relu(x)) ----------------------------------------------------------------------
+// Forward: one pass instead of relu + dropout (+ a saved bool mask).  Backward: dx = dy / (1 - p) where y != 0 (y is
+// non-zero exactly where the unit was active AND kept, so neither x nor a mask is saved), fused with the column sums of
+// dx = the bias gradient of the Linear in front (replaces masked_scale + threshold_backward + a column-sum pass).
+namespace {
+
+constexpr int RD_THREADS = 256, RD_VEC = 8, RD_ROWS_PER_BLOCK = 64;
+
+__global__ void __launch_bounds__(RD_THREADS)
+k_relu_dropout_fwd(const uint4 *__restrict__ x, uint4 *__restrict__ y, int64_t n_vec, float inv_keep, uint32_t thr16, uint32_t s0,
+                   uint32_t s1, const uint64_t *seed_state) {
+    mix_seed_state(seed_state, s0, s1);
+    for (int64_t v = (int64_t)blockIdx.x * RD_THREADS + threadIdx.x; v < n_vec; v += (int64_t)gridDim.x * RD_THREADS) {
+        const uint4 in = x[v];
+        const uint32_t w[4] = {in.x, in.y, in.z, in.w};
+        uint32_t o[4];
+        for (int q = 0; q < 4; ++q) {
+            uint32_t hsh = (uint32_t)(4 * v + q) * 0x9E3779B1u ^ s0;
+            hsh ^= (uint32_t)((uint64_t)(4 * v + q) >> 32) * 0x85EBCA77u + s1;
+            hsh ^= hsh >> 16; hsh *= 0x7FEB352Du; hsh ^= hsh >> 15; hsh *= 0x846CA68Bu; hsh ^= hsh >> 16;
+            const float a = bf2f(w[q] & 0xFFFFu), b = bf2f(w[q] >> 16);
+            const float ya = (a > 0.f && (hsh & 0xFFFFu) >= thr16) ? a * inv_keep : 0.f;
+            const float yb = (b > 0.f && (hsh >> 16) >= thr16) ? b * inv_keep : 0.f;
+            o[q] = f2bf(ya) | (f2bf(yb) << 16);
+        }
+        y[v] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dy, y, dx: bf16 [T][F] (dx may alias dy); partial[blockIdx][F]
+__global__ void __launch_bounds__(RD_THREADS)
+k_relu_dropout_bwd(const uint4 *__restrict__ dy, const uint4 *__restrict__ y, uint4 *__restrict__ dx, float *__restrict__ partial,
+                   int64_t T, int F, float inv_keep) {
+    __shared__ float red[RD_THREADS][RD_VEC];
+    const int cols_v = F / RD_VEC, rows_per_pass = RD_THREADS / cols_v;
+    const int cv = threadIdx.x % cols_v, rr = threadIdx.x / cols_v;
+    float acc[RD_VEC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t row0 = (int64_t)blockIdx.x * RD_ROWS_PER_BLOCK;
+    if (rr < rows_per_pass) {
+        for (int r = rr; r < RD_ROWS_PER_BLOCK; r += rows_per_pass) {
+            const int64_t row = row0 + r;
+            if (row >= T) break;
+            const int64_t v = row * cols_v + cv;
+            const uint4 g = dy[v], yy = y[v];
+            const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, yw[4] = {yy.x, yy.y, yy.z, yy.w};
+            uint32_t o[4];
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t lo = (yw[q] & 0x7FFFu) ? f2bf(bf2f(gw[q] & 0xFFFFu) * inv_keep) : 0u;
+                const uint32_t hi = (yw[q] & 0x7FFF0000u) ? f2bf(bf2f(gw[q] >> 16) * inv_keep) : 0u;
+                acc[2 * q] += bf2f(lo);
+                acc[2 * q + 1] += bf2f(hi);
+                o[q] = lo | (hi << 16);
+            }
+            dx[v] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    for (int q = 0; q < RD_VEC; ++q) red[threadIdx.x][q] = acc[q];
+    __syncthreads();
+    if (rr == 0) {
+        for (int k = 1; k < rows_per_pass; ++k)
+            for (int q = 0; q < RD_VEC; ++q) acc[q] += red[threadIdx.x + k * cols_v][q];
+        float *dst = partial + (int64_t)blockIdx.x * F + RD_VEC * cv;
+        reinterpret_cast<float4 *>(dst)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        reinterpret_cast<float4 *>(dst)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+inline bool rd_shape_ok(int64_t T, int F) { return T > 0 && F >= RD_VEC && F % RD_VEC == 0 && F / RD_VEC <= RD_THREADS; }
+
+}  // namespace
+
+extern "C" int g2048_relu_dropout_fwd(const void *x, void *y, int64_t T, int F, float p_drop, uint64_t seed,
+                                      const uint64_t *seed_state, void *stream) {
+    if (!x || !y || !rd_shape_ok(T, F) || !(p_drop >= 0.f && p_drop < 1.f) || (((uintptr_t)x | (uintptr_t)y) & 15)) return G2048_EINVAL;
+    const int64_t n_vec = T * (F / RD_VEC);
+    int64_t blocks = (n_vec + RD_THREADS - 1) / RD_THREADS;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_relu_dropout_fwd, dim3((unsigned)blocks), dim3(RD_THREADS), 0, (hipStream_t)stream, (const uint4 *)x, (uint4 *)y,
+                       n_vec, 1.0f / (1.0f - p_drop), (uint32_t)(p_drop * 65536.0f + 0.5f), (uint32_t)seed, (uint32_t)(seed >> 32),
+                       seed_state);
+    return done();
+}
+
+extern "C" int64_t g2048_relu_dropout_bwd_workspace_floats(int64_t T, int F) {
+    return rd_shape_ok(T, F) ? ((T + RD_ROWS_PER_BLOCK - 1) / RD_ROWS_PER_BLOCK) * F : 0;
+}
+
+extern "C" int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, float *workspace, int64_t T, int F,
+                                      float p_drop, void *stream) {
+    if (!dy || !y || !dx || !dbias || !workspace || !rd_shape_ok(T, F) || !(p_drop >= 0.f && p_drop < 1.f) ||
+        (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)workspace) & 15))
+        return G2048_EINVAL;
+    const int64_t blocks = (T + RD_ROWS_PER_BLOCK - 1) / RD_ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(k_relu_dropout_bwd, dim3((unsigned)blocks), dim3(RD_THREADS), 0, (hipStream_t)stream, (const uint4 *)dy,
+                       (const uint4 *)y, (uint4 *)dx, workspace, T, F, 1.0f / (1.0f - p_drop));
+    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((F + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, workspace, (int)blocks, F,
+                       dbias);
     return done();
 }

@@ -51,8 +51,12 @@ SIGNATURES = {
                        _vp, _vp],
     "g2048_colsum_workspace_floats": [_i64, _i32],
     "g2048_colsum": [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp],
+    "g2048_add_ln_bwd_workspace_floats": [_i64],
     "g2048_add_ln_bwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp,
                          _vp],
+    "g2048_relu_dropout_fwd": [_vp, _vp, _i64, _i32, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_relu_dropout_bwd_workspace_floats": [_i64, _i32],
+    "g2048_relu_dropout_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, C.c_float, _vp],
 }
 
 _lib = None
@@ -76,7 +80,7 @@ def load() -> C.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
-            fn.restype = C.c_int
+            fn.restype = C.c_int64 if name.endswith("_workspace_floats") else C.c_int
         if lib.g2048_abi_version() != 1:
             raise NativeError("libg2048.so ABI version mismatch")
         _lib = lib
@@ -284,16 +288,35 @@ def add_ln_fwd(x_ptr: int, x_row_stride: int, a, gamma, beta, x_new, h, mean, rs
                                    int(seed), seed_state or None, _stream()), "g2048_add_ln_fwd")
 
 
-def add_ln_bwd(xn_ptr: int, x_row_stride: int, g_x, g_h, mean, rstd, gamma, dx, da, dgamma, dbeta, T: int,
+def add_ln_bwd(xn_ptr: int, x_row_stride: int, g_x, g_h, mean, rstd, gamma, dx, da, dparams, T: int,
                p_drop: float, seed: int, seed_state: int = 0):
+    """dparams f32 [3, 256]: dgamma, dbeta, column sums of da."""
     bf = torch.bfloat16
+    ws = torch.empty(load().g2048_add_ln_bwd_workspace_floats(T), dtype=f32, device=dx.device)
     _check(load().g2048_add_ln_bwd(xn_ptr, int(x_row_stride), _dev(g_x, f32, 256 * T, "g_x", optional=True),
                                    _dev(g_h, bf, 256 * T, "g_h"), _dev(mean, f32, T, "mean"), _dev(rstd, f32, T, "rstd"),
                                    _dev(gamma, f32, 256, "gamma"), _dev(dx, f32, 256 * T, "dx"),
-                                   _dev(da, bf, 256 * T, "da", optional=True), _dev(dgamma, f32, 256, "dgamma"),
-                                   _dev(dbeta, f32, 256, "dbeta"), T, float(p_drop), int(seed), seed_state or None,
-                                   _stream()),
+                                   _dev(da, bf, 256 * T, "da", optional=True), _dev(dparams, f32, 768, "dparams"),
+                                   ws.data_ptr(), T, float(p_drop), int(seed), seed_state or None, _stream()),
            "g2048_add_ln_bwd")
+
+
+def relu_dropout_fwd(x, y, p_drop: float, seed: int, seed_state: int = 0):
+    bf = torch.bfloat16
+    F = x.shape[-1]
+    T = x.numel() // F
+    _check(load().g2048_relu_dropout_fwd(_dev(x, bf, T * F, "x"), _dev(y, bf, T * F, "y"), T, F, float(p_drop), int(seed),
+                                         seed_state or None, _stream()), "g2048_relu_dropout_fwd")
+
+
+def relu_dropout_bwd(dy, y, dx, dbias, p_drop: float):
+    bf = torch.bfloat16
+    F = y.shape[-1]
+    T = y.numel() // F
+    ws = torch.empty(load().g2048_relu_dropout_bwd_workspace_floats(T, F), dtype=f32, device=y.device)
+    _check(load().g2048_relu_dropout_bwd(_dev(dy, bf, T * F, "dy"), _dev(y, bf, T * F, "y"), _dev(dx, bf, T * F, "dx"),
+                                         _dev(dbias, f32, F, "dbias"), ws.data_ptr(), T, F, float(p_drop), _stream()),
+           "g2048_relu_dropout_bwd")
 
 
 COLSUM_MAX_GROUPS = 512
@@ -307,7 +330,7 @@ def colsum(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     T, N = x.shape
     if out is None:
         out = torch.empty(N, dtype=f32, device=x.device)
-    ws = torch.empty(COLSUM_MAX_GROUPS * N, dtype=f32, device=x.device)
+    ws = torch.empty(load().g2048_colsum_workspace_floats(T, N), dtype=f32, device=x.device)
     _check(load().g2048_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), x.stride(0), T, N, ws.data_ptr(),
                                _dev(out, f32, N, "out"), _stream()), "g2048_colsum")
     return out

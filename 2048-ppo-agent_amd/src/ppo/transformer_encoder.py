@@ -269,10 +269,7 @@ class _AddLayerNorm(torch.autograd.Function):
     def forward(ctx, x, a, gamma, beta, eps, p_drop):
         from ..g2048 import native as nv
 
-        if x.dim() == 3 and x.shape[1] == 1 and x.stride(2) == 1 and x.stride(0) % 4 == 0:
-            row_stride = x.stride(0)
-        else:
-            x, row_stride = x.contiguous(), x.shape[-1]
+        x, row_stride = _residual_rows(x)
         T = x.numel() // 256
         gamma, beta = gamma.contiguous(), beta.contiguous()
         h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
@@ -303,13 +300,97 @@ class _AddLayerNorm(torch.autograd.Function):
         T = xn.numel() // 256
         dx = torch.empty(xn.shape, dtype=torch.float32, device=xn.device)
         da = torch.empty(xn.shape, dtype=torch.bfloat16, device=xn.device) if has_a else None
-        dgb = torch.zeros((2, 256), dtype=torch.float32, device=xn.device)
+        dparams = torch.empty((3, 256), dtype=torch.float32, device=xn.device)
         if g_h is None:
             g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
         g_x = g_x.contiguous() if (has_a and g_x is not None) else None
-        nv.add_ln_bwd(xn.data_ptr(), row_stride, g_x, g_h.contiguous(), stats[0], stats[1], gamma, dx, da, dgb[0], dgb[1], T,
-                      p_drop, *seed)
-        return dx, da, dgb[0], dgb[1], None, None
+        nv.add_ln_bwd(xn.data_ptr(), row_stride, g_x, g_h.contiguous(), stats[0], stats[1], gamma, dx, da, dparams, T, p_drop,
+                      *seed)
+        return dx, da, dparams[0], dparams[1], None, None
+
+
+def _residual_rows(x: torch.Tensor):
+    """(x, row stride): a [B, 1, 256] slice of the residual stream is read in place by the add+LayerNorm kernels."""
+    if x.dim() == 3 and x.shape[1] == 1 and x.stride(2) == 1 and x.stride(0) % 4 == 0:
+        return x, x.stride(0)
+    return x.contiguous(), x.shape[-1]
+
+
+class _LinearAddLayerNorm(torch.autograd.Function):
+    """``a = Linear(u); x_new = x + dropout(a); h = LayerNorm(x_new).bfloat16()``: the closing Linear of a sub-layer
+    (out_proj / linear2) fused with ``_AddLayerNorm``.  The Linear's bias gradient (column sums of da) comes out of
+    ``g2048_add_ln_bwd`` for free, its weight gradient is the split-K product.  u bf16, wb/bb bf16 shadows of the f32
+    masters weight/bias, x f32; returns (x_new, h)."""
+
+    @staticmethod
+    def forward(ctx, u, weight, bias, wb, bb, x, gamma, beta, eps, p_drop):
+        from ..g2048 import native as nv
+
+        with torch.autocast("cuda", enabled=False):
+            a = F.linear(u, wb, bb)
+        x, row_stride = _residual_rows(x)
+        T = x.numel() // 256
+        gamma, beta = gamma.contiguous(), beta.contiguous()
+        h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        x_new = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        stats = torch.empty((2, T), dtype=torch.float32, device=x.device)
+        seed = _seed_pair(x, p_drop)
+        nv.add_ln_fwd(x.data_ptr(), row_stride, a, gamma, beta, x_new, h, stats[0], stats[1], T, eps, p_drop, *seed)
+        ctx.save_for_backward(u, wb, x_new, gamma, stats)
+        ctx.meta = (p_drop, seed)
+        return x_new, h
+
+    @staticmethod
+    def backward(ctx, g_x, g_h):
+        from ..g2048 import native as nv
+
+        u, wb, xn, gamma, stats = ctx.saved_tensors
+        p_drop, seed = ctx.meta
+        T = xn.numel() // 256
+        dx = torch.empty(xn.shape, dtype=torch.float32, device=xn.device)
+        da = torch.empty(xn.shape, dtype=torch.bfloat16, device=xn.device)
+        dparams = torch.empty((3, 256), dtype=torch.float32, device=xn.device)
+        if g_h is None:
+            g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
+        nv.add_ln_bwd(xn.data_ptr(), 256, None if g_x is None else g_x.contiguous(), g_h.contiguous(), stats[0], stats[1],
+                      gamma, dx, da, dparams, T, p_drop, *seed)
+        with torch.autocast("cuda", enabled=False):
+            da2, u2 = da.view(T, 256), u.reshape(T, -1)
+            du = (da2 @ wb).view(u.shape) if ctx.needs_input_grad[0] else None
+            dw = _dweight(da2, u2)
+        return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None
+
+
+class _LinearReluDropout(torch.autograd.Function):
+    """``dropout(relu(Linear(h)))`` (linear1 of the feed-forward block): the activation is one kernel each way
+    (``g2048_relu_dropout_fwd/bwd``), only the OUTPUT is saved (it is non-zero exactly where the unit was active and
+    kept), and the backward kernel also yields the bias gradient."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, wb, bb, p_drop):
+        from ..g2048 import native as nv
+
+        with torch.autocast("cuda", enabled=False):
+            z = F.linear(h, wb, bb)
+        y = torch.empty_like(z)
+        nv.relu_dropout_fwd(z, y, p_drop, *_seed_pair(z, p_drop))
+        ctx.save_for_backward(h, wb, y)
+        ctx.p_drop = p_drop
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ..g2048 import native as nv
+
+        h, wb, y = ctx.saved_tensors
+        dz = torch.empty_like(y)
+        db = torch.empty(y.shape[-1], dtype=torch.float32, device=y.device)
+        nv.relu_dropout_bwd(dy.contiguous(), y, dz, db, ctx.p_drop)
+        with torch.autocast("cuda", enabled=False):
+            dz2, h2 = dz.view(-1, dz.shape[-1]), h.reshape(-1, h.shape[-1])
+            dh = (dz2 @ wb).view(h.shape) if ctx.needs_input_grad[0] else None
+            dw = _dweight(dz2, h2)
+        return dh, dw, db, None, None, None
 
 
 def _fused_norm_ok(x: torch.Tensor, a) -> bool:
@@ -449,6 +530,18 @@ class TransformerEncoder(nn.Module):
                 q, k, v = qkv.view(B, S, 3, H, D // H).unbind(dim=2)
                 a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
                                                    dropout_p=p).transpose(1, 2).reshape(B, S, D)
+        if sh[0] is not None and a.dtype == torch.bfloat16 and _fused_norm_ok(x, None) \
+                and layer.linear1.out_features % 8 == 0 and layer.linear1.out_features <= 2048:
+            # update path: out_proj + add + LayerNorm, linear1 + ReLU + dropout, linear2 + add + LayerNorm as three ops
+            n2 = layer.norm2
+            x, h = _LinearAddLayerNorm.apply(a, attn.out_proj.weight, attn.out_proj.bias, sh[2], sh[3], x, n2.weight,
+                                             n2.bias, n2.eps, p)
+            f = _LinearReluDropout.apply(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5], p)
+            if next_norm is None:
+                f = _linear(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7])
+                return x + F.dropout(f, p, self.training), None
+            return _LinearAddLayerNorm.apply(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7], x, next_norm.weight,
+                                             next_norm.bias, next_norm.eps, p)
         a = _linear(a, attn.out_proj.weight, attn.out_proj.bias, sh[2], sh[3])
         x, h = _add_norm(x, a, layer.norm2, p, self.training)
         f = F.dropout(F.relu(_linear(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5])), p, self.training)

@@ -178,10 +178,12 @@ int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void *a, const 
                      uint64_t seed, const uint64_t *seed_state, void *stream);
 /* x_norm = the tensor that was normalised (x_new, or x when a was NULL); g_x f32 [T][256] or NULL = gradient arriving
  * on x_new from the residual stream; g_h bf16 [T][256].  dx f32 [T][256] = g_x + dLayerNorm (gradient for x);
- * da bf16 [T][256] or NULL = dropout-masked dx (gradient for a); dgamma/dbeta f32 [256] are ACCUMULATED into
- * (float atomics): zero them first. */
+ * da bf16 [T][256] or NULL = dropout-masked dx (gradient for a); dparams f32 [3][256] = dgamma, dbeta and the column
+ * sums of da (= the bias gradient of the Linear that produced a; zeros when da is NULL), summed in a fixed order;
+ * workspace: g2048_add_ln_bwd_workspace_floats(T) floats of scratch. */
+int64_t g2048_add_ln_bwd_workspace_floats(int64_t T);
 int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
-                     const float *rstd, const float *gamma, float *dx, void *da, float *dgamma, float *dbeta,
+                     const float *rstd, const float *gamma, float *dx, void *da, float *dparams, float *workspace,
                      int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
 
 /* ---- policy network (update): bias gradients ------------------------------------------------------------ */
@@ -192,7 +194,7 @@ int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x
  * src/ppo/transformer_encoder.py:138-148 and src/ppo/ppo_agent.py:59-86; PyTorch computes it with at::sum).
  * workspace: g2048_colsum_workspace_floats(T, N) floats of scratch. */
 #define G2048_COLSUM_MAX_GROUPS 512
-int g2048_colsum_workspace_floats(int64_t T, int N);
+int64_t g2048_colsum_workspace_floats(int64_t T, int N);
 int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int64_t T, int N, float *workspace, float *out,
                  void *stream);
 
@@ -210,6 +212,20 @@ int g2048_ppo_loss(const void *logits, int logits_bf16, const void *values, int 
                    const uint8_t *mask_bits, const float *old_logp, const float *adv, const float *ret, int64_t M,
                    float clip_eps, float c_value, float c_entropy, float *new_logp, float *sums, void *dlogits,
                    void *dvalues, void *stream);
+
+/* ---- policy network (update): feed-forward activation ---------------------------------------------------- */
+
+/* y = dropout(relu(x)), x and y bf16 [T][F] (F a multiple of 8, F <= 2048): `dropout(activation(linear1(x)))` of the
+ * encoder layer's feed-forward block (reference: nn.TransformerEncoderLayer, src/ppo/transformer_encoder.py:138-148).
+ * seed, seed_state: as for g2048_attn_fwd. */
+int g2048_relu_dropout_fwd(const void *x, void *y, int64_t T, int F, float p_drop, uint64_t seed,
+                           const uint64_t *seed_state, void *stream);
+/* dx = dy / (1 - p_drop) where y != 0, else 0 (y is non-zero exactly where the unit was active and kept: neither x nor
+ * a mask is needed); dbias f32 [F] = column sums of dx in a fixed order = the bias gradient of the Linear in front.
+ * dx may alias dy.  workspace: g2048_relu_dropout_bwd_workspace_floats(T, F) floats. */
+int64_t g2048_relu_dropout_bwd_workspace_floats(int64_t T, int F);
+int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, float *workspace, int64_t T, int F,
+                           float p_drop, void *stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def _declared():
     text = open(os.path.join(ROOT, "include", "g2048.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(g2048_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(g2048_\w+)\s*\(", text)))
 
 
 def test_header_symbols_are_exported_and_bound():

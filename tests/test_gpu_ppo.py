@@ -442,3 +442,90 @@ def test_fused_ppo_loss_matches_torch(dev, dtype, use_mask):
         assert torch.allclose(dv.float(), v32.grad, **gtol)
         assert torch.equal(sums, nv.ppo_loss(logits, values, actions.to(torch.uint8), bits if use_mask else None, old_lp, adv,
                                              ret, 0.2, 0.5, 0.01)[1])  # fixed summation order
+
+
+def test_relu_dropout_kernels(dev):
+    """g2048_relu_dropout_fwd/bwd: exact ReLU at p = 0; with dropout the kept share of the active units, the 1/(1-p)
+    scale and a fresh mask per call; backward = dy/(1-p) where y != 0, plus its column sums (the bias gradient)."""
+    from src.g2048 import native as nv
+
+    torch.manual_seed(7)
+    for T, Fdim in ((1, 8), (37, 64), (4097, 1024), (130, 2048)):
+        x = torch.randn(T, Fdim, device=dev).to(torch.bfloat16)
+        y = torch.empty_like(x)
+        nv.relu_dropout_fwd(x, y, 0.0, 0)
+        assert torch.equal(y, torch.relu(x))
+        dy = torch.randn(T, Fdim, device=dev).to(torch.bfloat16)
+        dx, db = torch.empty_like(dy), torch.empty(Fdim, device=dev)
+        nv.relu_dropout_bwd(dy, y, dx, db, 0.0)
+        want = torch.where(y != 0, dy, torch.zeros_like(dy))
+        assert torch.equal(dx, want)
+        assert torch.allclose(db, want.float().sum(0), rtol=1e-4, atol=1e-3)
+    x = (torch.randn(4096, 1024, device=dev)).to(torch.bfloat16)
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    nv.relu_dropout_fwd(x, y1, 0.1, 123)
+    nv.relu_dropout_fwd(x, y2, 0.1, 124)
+    active = x > 0
+    kept = (y1 != 0)
+    assert not (kept & ~active).any()
+    assert abs(kept[active].float().mean().item() - 0.9) < 2e-3 and not torch.equal(y1, y2)
+    assert torch.allclose(y1[kept].float(), (x[kept].float() / 0.9), rtol=1e-2)
+    assert (kept.float().sum(0) / active.float().sum(0) - 0.9).abs().max() < 0.05  # no structure along columns
+    dy = torch.randn_like(x)
+    dx, db = torch.empty_like(dy), torch.empty(1024, device=dev)
+    nv.relu_dropout_bwd(dy, y1, dx, db, 0.1)
+    want = torch.where(kept, (dy.float() / 0.9).to(torch.bfloat16), torch.zeros_like(dy))
+    assert (dx.float() - want.float()).abs().max() <= 2.0 ** -7 * want.float().abs().max()  # 1 bf16 ulp (rounding of 1/(1-p))
+    assert torch.allclose(db, dx.float().sum(0), rtol=1e-4, atol=1e-2)
+    nv.relu_dropout_bwd(dy, y1, dy, db, 0.1)  # in place
+    assert torch.equal(dy, dx)
+
+
+def test_fused_linear_blocks_match_torch(dev):
+    """_LinearAddLayerNorm and _LinearReluDropout (dropout off) vs the PyTorch composition under bf16 autocast semantics:
+    outputs and every gradient, incl. the bias gradients that come out of the add+LN / activation backward kernels and
+    the strided [B, 1, 256] residual slice of the CLS-only layer."""
+    import torch.nn.functional as F
+
+    from src.ppo.transformer_encoder import _LinearAddLayerNorm, _LinearReluDropout
+
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+    torch.manual_seed(11)
+    for B, S, K, sliced in ((64, 17, 256, False), ((2048, 17, 1024, False)), (300, 1, 256, True)):
+        u = torch.randn(B, S, K, device=dev).to(torch.bfloat16).requires_grad_(True)
+        w = (torch.randn(256, K, device=dev) / K ** 0.5).requires_grad_(True)
+        b = (0.1 * torch.randn(256, device=dev)).requires_grad_(True)
+        base = torch.randn(B, 17 if sliced else S, 256, device=dev).requires_grad_(True)
+        x = base[:, :1] if sliced else base
+        gamma = (1 + 0.1 * torch.randn(256, device=dev)).requires_grad_(True)
+        beta = (0.1 * torch.randn(256, device=dev)).requires_grad_(True)
+        gx, gh = torch.randn(x.shape, device=dev), torch.randn(x.shape, device=dev).to(torch.bfloat16)
+        leaves = (u, w, b, base, gamma, beta)
+        x_new, h = _LinearAddLayerNorm.apply(u, w, b, w.detach().to(torch.bfloat16), b.detach().to(torch.bfloat16), x, gamma,
+                                             beta, 1e-5, 0.0)
+        torch.autograd.backward([x_new, h], [gx, gh])
+        got = [t.grad.clone() for t in leaves]
+        for t in leaves:
+            t.grad = None
+        a = F.linear(u, w.to(torch.bfloat16), b.to(torch.bfloat16))
+        xr = x + a.float()
+        hr = F.layer_norm(xr, (256,), gamma, beta, 1e-5)
+        torch.autograd.backward([xr, hr], [gx, gh.float()])
+        assert torch.allclose(x_new, xr, atol=1e-5) and rel(h, hr) < 3e-3
+        for name, g, t in zip(("u", "w", "b", "x", "gamma", "beta"), got, leaves):
+            assert rel(g, t.grad) < (8e-3 if name in ("u", "w", "b") else 2e-4), (name, rel(g, t.grad))
+    for T, K, Fdim in ((64, 256, 1024), (34816, 256, 1024), (300, 256, 512)):
+        hh = torch.randn(T, K, device=dev).to(torch.bfloat16).requires_grad_(True)
+        w = (torch.randn(Fdim, K, device=dev) / K ** 0.5).requires_grad_(True)
+        b = (0.1 * torch.randn(Fdim, device=dev)).requires_grad_(True)
+        gy = torch.randn(T, Fdim, device=dev).to(torch.bfloat16)
+        y = _LinearReluDropout.apply(hh, w, b, w.detach().to(torch.bfloat16), b.detach().to(torch.bfloat16), 0.0)
+        y.backward(gy)
+        got = [t.grad.clone() for t in (hh, w, b)]
+        for t in (hh, w, b):
+            t.grad = None
+        yr = torch.relu(F.linear(hh, w.to(torch.bfloat16), b.to(torch.bfloat16)))
+        yr.backward(gy)
+        assert torch.equal(y, yr)
+        for name, g, t in zip(("h", "w", "b"), got, (hh, w, b)):
+            assert rel(g, t.grad) < 8e-3, (name, rel(g, t.grad))
