@@ -12,7 +12,8 @@ SRC_POLICY = os.path.join(HERE, "csrc", "g2048_policy.hip")
 SRC_ATTN = os.path.join(HERE, "csrc", "g2048_attention.hip")
 SRC_LN = os.path.join(HERE, "csrc", "g2048_layernorm.hip")
 SRC_LOSS = os.path.join(HERE, "csrc", "g2048_ppo_loss.hip")
-DEPS = [SRC, SRC_POLICY, SRC_ATTN, SRC_LN, SRC_LOSS, os.path.join(HERE, "csrc", "g2048_device.h"), os.path.join(HERE, "..", "include", "g2048.h")]
+SRC_LIN = os.path.join(HERE, "csrc", "g2048_linear.hip")
+DEPS = [SRC, SRC_POLICY, SRC_ATTN, SRC_LN, SRC_LOSS, SRC_LIN, os.path.join(HERE, "csrc", "g2048_device.h"), os.path.join(HERE, "..", "include", "g2048.h")]
 OUT = os.path.join(HERE, "lib", "libg2048.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -21,7 +22,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    cmd = ["hipcc", *FLAGS, "-o", OUT, SRC, SRC_POLICY, SRC_ATTN, SRC_LN, SRC_LOSS]
+    cmd = ["hipcc", *FLAGS, "-o", OUT, SRC, SRC_POLICY, SRC_ATTN, SRC_LN, SRC_LOSS, SRC_LIN]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

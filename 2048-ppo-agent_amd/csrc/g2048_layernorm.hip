@@ -200,19 +200,30 @@ k_colsum_partial(const void *__restrict__ x, int64_t rs, int64_t T, int N, float
     }
 }
 
-// 64 columns per workgroup, 16 interleaved slices of the G partial rows per column, combined through LDS in a fixed order
-__global__ void __launch_bounds__(1024)
+// 32 columns per workgroup, 32 interleaved slices of the G partial rows per column (4 independent loads in flight per
+// thread), combined through LDS in a fixed order
+constexpr int CF_COLS = 32, CF_SLICES = 32;
+__global__ void __launch_bounds__(CF_COLS * CF_SLICES)
 k_colsum_final(const float *__restrict__ partial, int G, int N, float *__restrict__ out) {
-    __shared__ float red[16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c < N)
-        for (int g = slice; g < G; g += 16) s += partial[(int64_t)g * N + c];
-    red[slice][threadIdx.x & 63] = s;
+    __shared__ float red[CF_SLICES][CF_COLS];
+    const int cl = threadIdx.x % CF_COLS, slice = threadIdx.x / CF_COLS, c = blockIdx.x * CF_COLS + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < N) {
+        const float *p = partial + c;
+        int g = slice;
+        for (; g + 3 * CF_SLICES < G; g += 4 * CF_SLICES) {
+            s0 += p[(int64_t)g * N];
+            s1 += p[(int64_t)(g + CF_SLICES) * N];
+            s2 += p[(int64_t)(g + 2 * CF_SLICES) * N];
+            s3 += p[(int64_t)(g + 3 * CF_SLICES) * N];
+        }
+        for (; g < G; g += CF_SLICES) s0 += p[(int64_t)g * N];
+    }
+    red[slice][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (slice == 0 && c < N) {
         float t = 0.f;
-        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        for (int k = 0; k < CF_SLICES; ++k) t += red[k][cl];
         out[c] = t;
     }
 }
@@ -241,7 +252,7 @@ extern "C" int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int6
     else
         hipLaunchKernelGGL(k_colsum_partial<false>, dim3((unsigned)G), dim3(CS_THREADS), 0, (hipStream_t)stream, x, row_stride, T, N,
                            workspace);
-    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, workspace, (int)G, N,
+    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream, workspace, (int)G, N,
                        out);
     return done();
 }
@@ -262,7 +273,8 @@ extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const
     hipLaunchKernelGGL(k_add_ln_bwd, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream, x_norm, x_row_stride, g_x,
                        (const uint16_t *)g_h, mean, rstd, gamma, dx, (uint16_t *)da, workspace, T, 1.0f / (1.0f - p_drop), thr,
                        (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
-    hipLaunchKernelGGL(k_colsum_final, dim3(3 * D / 64), dim3(1024), 0, (hipStream_t)stream, workspace, (int)blocks, 3 * D, dparams);
+    hipLaunchKernelGGL(k_colsum_final, dim3(3 * D / CF_COLS), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream, workspace, (int)blocks, 3 * D,
+                       dparams);
     return done();
 }
 
@@ -361,7 +373,7 @@ extern "C" int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, f
     const int64_t blocks = (T + RD_ROWS_PER_BLOCK - 1) / RD_ROWS_PER_BLOCK;
     hipLaunchKernelGGL(k_relu_dropout_bwd, dim3((unsigned)blocks), dim3(RD_THREADS), 0, (hipStream_t)stream, (const uint4 *)dy,
                        (const uint4 *)y, (uint4 *)dx, workspace, T, F, 1.0f / (1.0f - p_drop));
-    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((F + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, workspace, (int)blocks, F,
+    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((F + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream, workspace, (int)blocks, F,
                        dbias);
     return done();
 }

@@ -1,0 +1,222 @@
+// Y[T][N] = X[T][K] . W[N][K]^T (+ bias) in bf16 with f32 accumulation: nn.Linear for tall-skinny activations
+// (T = 34 816 tokens per PPO minibatch, K and N in {256, 512, 768, 1024}) on gfx950 MFMA.
+//
+// hipBLASLt runs these shapes at 130-360 TFLOP/s (35 us for 34816x256x256, whose operands are 36 MB); they are really
+// bandwidth problems with tiny weights.  Layout of this kernel:
+//   * computed transposed, like the rollout encoder: Y^T[n][token] = W[n][k] . X^T[k][token] with
+//     v_mfma_f32_32x32x16_bf16 - the weight tile is the A operand in nn.Linear's own [N][K] layout, tokens sit on lanes;
+//   * a workgroup (4 waves) owns 128 tokens x a 128-wide slice of N; its weight slice streams L2 -> LDS by LDS-DMA in
+//     K-chunks of 128 (32 KiB, XOR-swizzled so that every A fragment is one conflict-free ds_read_b128), two chunks in
+//     flight; 64 KiB of LDS per workgroup = two workgroups per CU, so one's weight stream hides behind the other's MFMAs;
+//   * the B operand (8 consecutive k of one token per lane) is loaded straight from global memory, 16 bytes per lane
+//     per k-step - each lane walks its own row, the rows of a wave stay L1-resident across the K loop;
+//   * epilogue: lanes l and l+32 exchange half their accumulators (v_permlane32_swap) so that every lane owns 64
+//     consecutive outputs of its token = 128 contiguous bytes, adds the bias and stores bf16.
+// The same kernel computes dX = dY . W with the transposed weight W^T[K][N] as its "weight".
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/g2048.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TOK = 128, NS = 128, KC = 128, THREADS = 256;
+constexpr int CHUNK_BYTES = NS * KC * 2;  // one K-chunk of the weight slice: 32 KiB
+constexpr int NBUF = 2;
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (uint32_t) * reinterpret_cast<const uint16_t *>(&x) | ((uint32_t) * reinterpret_cast<const uint16_t *>(&y) << 16);
+}
+
+// LDS image of a chunk: [128 rows n][16 chunks of 16 B], chunk q of row r stored at q ^ (r & 15).
+// DMA: wave-instruction t of wave w fills LDS bytes [(4t + w) * 1024, +1024) = rows 4(4t + w) .. +3; lane i supplies
+// physical chunk p = i & 15 of row 4(4t + w) + (i >> 4).
+__device__ __forceinline__ void dma_chunk(char *dst, const __bf16 *w_slice, int64_t ldw, int kc, int w, int lane) {
+    const char *base = reinterpret_cast<const char *>(w_slice) + (size_t)kc * KC * 2;
+    for (int t = 0; t < NS / 16; ++t) {
+        const int row = 4 * (4 * t + w) + (lane >> 4);
+        const int q = (lane & 15) ^ (row & 15);
+        const char *g = base + (size_t)row * ldw * 2 + q * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(dst + (4 * t + w) * 1024), 16, 0, 0);
+    }
+}
+
+// Shared epilogue.  acc[j][i] = Y^T[n0 + 32j + (i&3) + 8(i>>2) + 4h][token r]: a lane holds columns 8g + 4h .. +3 of every
+// group g of 8.  Pack to bf16, then exchange between lane halves (v_permlane32_swap: lanes 32-63 of the first operand
+// swap with lanes 0-31 of the second) so that the lower half owns the even groups and the upper half the odd ones,
+// 8 consecutive outputs = one 16-byte store each.  Executed by all 64 lanes (the swap needs EXEC all ones).
+template <bool HAS_BIAS>
+__device__ __forceinline__ void store_tile(f32x16 acc[4], const float *__restrict__ bias, __bf16 *yrow, int n0, int h, bool valid) {
+    for (int j = 0; j < 4; ++j) {
+        if (HAS_BIAS)
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bias + n0 + 32 * j + 8 * g + 4 * h);
+                acc[j][4 * g + 0] += bv.x; acc[j][4 * g + 1] += bv.y; acc[j][4 * g + 2] += bv.z; acc[j][4 * g + 3] += bv.w;
+            }
+        for (int m = 0; m < 2; ++m) {
+            uint32_t ax = pack2(acc[j][8 * m + 0], acc[j][8 * m + 1]), ay = pack2(acc[j][8 * m + 2], acc[j][8 * m + 3]);
+            uint32_t bx = pack2(acc[j][8 * m + 4], acc[j][8 * m + 5]), by = pack2(acc[j][8 * m + 6], acc[j][8 * m + 7]);
+            const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            if (valid) *reinterpret_cast<uint4 *>(yrow + 32 * j + 16 * m) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+    }
+}
+
+// K > 256: the weight slice streams through two LDS buffers once per 128-token tile.
+template <bool HAS_BIAS>
+__global__ void __launch_bounds__(THREADS, 2)
+k_linear(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ wgt, int64_t ldw, const float *__restrict__ bias,
+         __bf16 *__restrict__ y, int64_t ldy, int64_t T, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int64_t tok0 = (int64_t)blockIdx.x * TOK + 32 * w;
+    const int n0 = blockIdx.y * NS;
+    const __bf16 *w_slice = wgt + (size_t)n0 * ldw;
+    const int n_chunks = K / KC;
+
+    // this lane's token row (clamped: rows past T are computed on row T-1 and not stored)
+    int64_t tok = tok0 + r;
+    const bool valid = tok < T;
+    if (!valid) tok = T - 1;
+    const uint4 *xrow = reinterpret_cast<const uint4 *>(x + tok * ldx) + h;  // chunk 2ks + h of the row
+
+    // vmcnt retires in issue order: the B operand of chunk c is always issued BEFORE the DMA of the chunk after it, so
+    // "at most 8 outstanding" below means: everything up to this chunk landed, only the next chunk's DMA may be in flight
+    uint4 bq[8];
+    for (int ks = 0; ks < 8; ++ks) bq[ks] = xrow[2 * ks];
+    dma_chunk(smem, w_slice, ldw, 0, w, lane);
+    if (n_chunks > 1) dma_chunk(smem + CHUNK_BYTES, w_slice, ldw, 1, w, lane);
+
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+    // A-fragment offsets inside a chunk image: row 32j + r, chunk (2ks + h) ^ (r & 15)
+    int aoff[8];
+    for (int ks = 0; ks < 8; ++ks) aoff[ks] = r * 256 + (((2 * ks + h) ^ (r & 15)) * 16);
+
+    for (int c = 0; c < n_chunks; ++c) {
+        // chunk c landed? (at most one younger chunk may still be in flight)
+        if (c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char *tile = smem + (c % NBUF) * CHUNK_BYTES;
+        bf16x8 b[8];
+        for (int ks = 0; ks < 8; ++ks) b[ks] = *reinterpret_cast<const bf16x8 *>(&bq[ks]);
+        if (c + 1 < n_chunks)
+            for (int ks = 0; ks < 8; ++ks) bq[ks] = xrow[2 * (8 * (c + 1) + ks)];  // next chunk's B operand
+        for (int ks = 0; ks < 8; ++ks)
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(tile + aoff[ks] + j * 32 * 256);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ks], acc[j], 0, 0, 0);
+            }
+        __syncthreads();  // every wave is done with this buffer
+        if (c + NBUF < n_chunks) dma_chunk(smem + (c % NBUF) * CHUNK_BYTES, w_slice, ldw, c + NBUF, w, lane);
+    }
+    store_tile<HAS_BIAS>(acc, bias, y + (tok0 + r) * ldy + n0 + 8 * h, n0, h, valid);
+}
+
+// K <= 256: the weight slice (<= 64 KiB) is loaded ONCE and stays in LDS; the workgroup then walks over token tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... with the next half-row of B always in flight behind the current MFMAs.
+template <bool HAS_BIAS>
+__global__ void __launch_bounds__(THREADS, 2)
+k_linear_stationary(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ wgt, int64_t ldw,
+                    const float *__restrict__ bias, __bf16 *__restrict__ y, int64_t ldy, int64_t T, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * NS;
+    const __bf16 *w_slice = wgt + (size_t)n0 * ldw;
+    const int n_chunks = K / KC;  // 1 or 2
+    const int64_t n_tiles = (T + TOK - 1) / TOK;
+
+    auto row_of = [&](int64_t tile) -> const uint4 * {
+        int64_t tok = tile * TOK + 32 * w + r;
+        if (tok >= T) tok = T - 1;
+        return reinterpret_cast<const uint4 *>(x + tok * ldx) + h;
+    };
+    const uint4 *xrow = row_of(blockIdx.x);
+    uint4 bq[8];
+    for (int ks = 0; ks < 8; ++ks) bq[ks] = xrow[2 * ks];
+    for (int c = 0; c < n_chunks; ++c) dma_chunk(smem + c * CHUNK_BYTES, w_slice, ldw, c, w, lane);
+    int aoff[8];
+    for (int ks = 0; ks < 8; ++ks) aoff[ks] = r * 256 + (((2 * ks + h) ^ (r & 15)) * 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t next = tile + gridDim.x;
+        const uint4 *xnext = row_of(next < n_tiles ? next : tile);
+        f32x16 acc[4];
+        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+        for (int c = 0; c < n_chunks; ++c) {
+            bf16x8 b[8];
+            for (int ks = 0; ks < 8; ++ks) b[ks] = *reinterpret_cast<const bf16x8 *>(&bq[ks]);
+            // prefetch: the other half of this row, or the first half of the next tile's row
+            const uint4 *src = (c + 1 < n_chunks) ? xrow + 16 * (c + 1) : xnext;
+            for (int ks = 0; ks < 8; ++ks) bq[ks] = src[2 * ks];
+            const char *img = smem + c * CHUNK_BYTES;
+            for (int ks = 0; ks < 8; ++ks)
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(img + aoff[ks] + j * 32 * 256);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ks], acc[j], 0, 0, 0);
+                }
+        }
+        const int64_t tok = tile * TOK + 32 * w + r;
+        store_tile<HAS_BIAS>(acc, bias, y + tok * ldy + n0 + 8 * h, n0, h, tok < T);
+        xrow = xnext;
+    }
+}
+
+}  // namespace
+
+extern "C" int g2048_linear_bf16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const float *bias, void *y,
+                                 int64_t ldy, int64_t T, int K, int N, void *stream) {
+    if (!x || !weight || !y || T <= 0 || K < KC || K % KC || N < NS || N % NS || ldx < K || ldw < K || ldy < N || (ldx & 7) ||
+        (ldw & 7) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)bias) & 15))
+        return G2048_EINVAL;
+    static bool attr_set = false;  // benign race: idempotent
+    if (!attr_set) {
+        const int lds = NBUF * CHUNK_BYTES;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_stationary<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_stationary<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int64_t n_tiles = (T + TOK - 1) / TOK;
+    const int slices = N / NS;
+    const __bf16 *xp = (const __bf16 *)x, *wp = (const __bf16 *)weight;
+    __bf16 *yp = (__bf16 *)y;
+    if (K <= NBUF * KC) {
+        // two workgroups per CU on 256 CUs, shared between the N-slices
+        int64_t groups = 512 / slices;
+        if (groups < 1) groups = 1;
+        if (groups > n_tiles) groups = n_tiles;
+        const dim3 grid((unsigned)groups, (unsigned)slices);
+        if (bias)
+            hipLaunchKernelGGL(k_linear_stationary<true>, grid, dim3(THREADS), (K / KC) * CHUNK_BYTES, (hipStream_t)stream, xp, ldx, wp,
+                               ldw, bias, yp, ldy, T, K);
+        else
+            hipLaunchKernelGGL(k_linear_stationary<false>, grid, dim3(THREADS), (K / KC) * CHUNK_BYTES, (hipStream_t)stream, xp, ldx, wp,
+                               ldw, bias, yp, ldy, T, K);
+    } else {
+        const dim3 grid((unsigned)n_tiles, (unsigned)slices);
+        if (bias)
+            hipLaunchKernelGGL(k_linear<true>, grid, dim3(THREADS), NBUF * CHUNK_BYTES, (hipStream_t)stream, xp, ldx, wp, ldw, bias, yp,
+                               ldy, T, K);
+        else
+            hipLaunchKernelGGL(k_linear<false>, grid, dim3(THREADS), NBUF * CHUNK_BYTES, (hipStream_t)stream, xp, ldx, wp, ldw, bias, yp,
+                               ldy, T, K);
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(1000 + (int)e);
+}

@@ -49,6 +49,7 @@ SIGNATURES = {
     "g2048_add_ln_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_ppo_loss": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp,
                        _vp, _vp],
+    "g2048_linear_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "g2048_colsum_workspace_floats": [_i64, _i32],
     "g2048_colsum": [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp],
     "g2048_add_ln_bwd_workspace_floats": [_i64],
@@ -353,3 +354,25 @@ def ppo_loss(logits, values, actions, mask_bits, old_logp, adv, ret, clip_eps: f
         _dev(adv, f32, M, "adv"), _dev(ret, f32, M, "ret"), M, float(clip_eps), float(c_value), float(c_entropy),
         new_logp.data_ptr(), sums.data_ptr(), dlogits.data_ptr(), dvalues.data_ptr(), _stream()), "g2048_ppo_loss")
     return new_logp, sums, dlogits, dvalues
+
+
+def linear_ok(x2: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes/strides g2048_linear_bf16 takes: x2 [T, K] and weight [N, K] bf16 on the device with contiguous rows."""
+    return (x2.is_cuda and x2.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x2.dim() == 2
+            and weight.dim() == 2 and x2.stride(1) == 1 and weight.stride(1) == 1 and x2.shape[1] == weight.shape[1]
+            and x2.shape[1] % 128 == 0 and weight.shape[0] % 128 == 0 and x2.stride(0) % 8 == 0 and weight.stride(0) % 8 == 0
+            and x2.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and x2.shape[0] > 0)
+
+
+def linear_bf16(x2: torch.Tensor, weight: torch.Tensor, bias_f32=None, out=None) -> torch.Tensor:
+    """out[T, N] (bf16) = x2[T, K] @ weight[N, K]^T (+ bias f32 [N])."""
+    if not linear_ok(x2, weight):
+        raise NativeError(f"linear_bf16: unsupported operands {tuple(x2.shape)} {x2.dtype} x {tuple(weight.shape)} {weight.dtype}")
+    T, K = x2.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty((T, N), dtype=torch.bfloat16, device=x2.device)
+    _check(load().g2048_linear_bf16(x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0),
+                                    _dev(bias_f32, f32, N, "bias", optional=True), _dev(out, torch.bfloat16, T * N, "out"), N, T,
+                                    K, N, _stream()), "g2048_linear_bf16")
+    return out

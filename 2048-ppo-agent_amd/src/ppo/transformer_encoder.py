@@ -23,9 +23,11 @@ class Bf16Shadow:
 
     _live = weakref.WeakSet()
 
-    def __init__(self, params):
+    def __init__(self, params, transposed=()):
         self.params = list(params)
         self.key, self.flat, self.views = None, None, None
+        self.transposed = tuple(transposed)  # indices of 2-D params that also get a [in, out] copy (``tviews[i]``)
+        self.tviews = {}
         Bf16Shadow._live.add(self)
 
     def invalidate(self):
@@ -49,8 +51,12 @@ class Bf16Shadow:
                     n += (q.numel() + 63) // 64 * 64  # keep every view 128-byte aligned for the GEMMs
                 self.flat = torch.empty(n, dtype=torch.bfloat16, device=ps[0].device)
                 self.views = [self.flat[o:o + q.numel()].view(q.shape) for o, q in zip(offs, ps)]
+                self.tviews = {i: torch.empty(ps[i].shape[::-1], dtype=torch.bfloat16, device=ps[0].device)
+                               for i in self.transposed}
             with torch.no_grad():
                 torch._foreach_copy_(self.views, [q.detach() for q in ps])
+                for i, tv in self.tviews.items():
+                    tv.copy_(self.views[i].t())
             self.key = key
         return self.views
 
@@ -83,6 +89,20 @@ class _ExpandRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return _colsum(g.reshape(g.shape[0], -1)).view(1, 1, -1), None
+
+
+def _hip_linear(x2: torch.Tensor, wb: torch.Tensor, bias_f32=None):
+    """x2 @ wb^T (+ bias) through ``g2048_linear_bf16`` for the shapes where its weights-stationary layout beats
+    hipBLASLt's pick on this chip (K <= 256 with a wide output: linear1 forward 55 -> 38 us, linear2 input gradient
+    48 -> 38 us at 34 816 tokens; tools/probe_linear.py), else None."""
+    K, N = x2.shape[-1], wb.shape[0]
+    if K > 256 or N < 512 or N % 256 or x2.shape[0] < 4096:
+        return None
+    from ..g2048 import native as nv
+
+    if not nv.linear_ok(x2, wb):
+        return None
+    return nv.linear_bf16(x2, wb, bias_f32)
 
 
 def _dweight(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
@@ -323,11 +343,12 @@ class _LinearAddLayerNorm(torch.autograd.Function):
     masters weight/bias, x f32; returns (x_new, h)."""
 
     @staticmethod
-    def forward(ctx, u, weight, bias, wb, bb, x, gamma, beta, eps, p_drop):
+    def forward(ctx, u, weight, bias, wb, bb, x, gamma, beta, eps, p_drop, wbT=None):
         from ..g2048 import native as nv
 
         with torch.autocast("cuda", enabled=False):
             a = F.linear(u, wb, bb)
+        ctx.wbT = wbT
         x, row_stride = _residual_rows(x)
         T = x.numel() // 256
         gamma, beta = gamma.contiguous(), beta.contiguous()
@@ -356,9 +377,12 @@ class _LinearAddLayerNorm(torch.autograd.Function):
                       gamma, dx, da, dparams, T, p_drop, *seed)
         with torch.autocast("cuda", enabled=False):
             da2, u2 = da.view(T, 256), u.reshape(T, -1)
-            du = (da2 @ wb).view(u.shape) if ctx.needs_input_grad[0] else None
+            du = None
+            if ctx.needs_input_grad[0]:
+                du = _hip_linear(da2, ctx.wbT) if ctx.wbT is not None else None
+                du = (da2 @ wb if du is None else du).view(u.shape)
             dw = _dweight(da2, u2)
-        return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None
+        return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None
 
 
 class _LinearReluDropout(torch.autograd.Function):
@@ -371,7 +395,8 @@ class _LinearReluDropout(torch.autograd.Function):
         from ..g2048 import native as nv
 
         with torch.autocast("cuda", enabled=False):
-            z = F.linear(h, wb, bb)
+            z = _hip_linear(h.reshape(-1, h.shape[-1]), wb, bias)
+            z = F.linear(h, wb, bb) if z is None else z.view(*h.shape[:-1], wb.shape[0])
         y = torch.empty_like(z)
         nv.relu_dropout_fwd(z, y, p_drop, *_seed_pair(z, p_drop))
         ctx.save_for_backward(h, wb, y)
@@ -487,18 +512,18 @@ class TransformerEncoder(nn.Module):
         (``Bf16Shadow``), else a list of None (``_linear`` then uses the masters directly)."""
         layers = self.encoder.layers
         if not _train_bf16(like, layers[0].linear1.weight):
-            return [[None] * 8 for _ in layers]
+            return [[None] * 9 for _ in layers]
         if self._shadow is None:
             ps = []
             for l in layers:
                 ps += [l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, l.self_attn.out_proj.weight,
                        l.self_attn.out_proj.bias, l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias]
-            self._shadow = Bf16Shadow(ps)
+            self._shadow = Bf16Shadow(ps, transposed=[8 * i + 6 for i in range(len(layers))])
         v = self._shadow()
-        return [v[8 * i:8 * i + 8] for i in range(len(layers))]
+        return [v[8 * i:8 * i + 8] + [self._shadow.tviews[8 * i + 6]] for i in range(len(layers))]
 
     def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor, h: torch.Tensor, next_norm,
-               cls_only: bool = False, sh=(None,) * 8):
+               cls_only: bool = False, sh=(None,) * 9):
         """One pre-norm encoder layer.  ``h`` = norm1(x), already computed (by the previous layer's tail); returns
         (x_out, next_norm(x_out)) so that every residual add + dropout + LayerNorm is one fused kernel
         (``_add_norm``); ``next_norm`` None: (x_out, None).  With ``cls_only`` only the CLS row of the output is
@@ -541,7 +566,7 @@ class TransformerEncoder(nn.Module):
                 f = _linear(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7])
                 return x + F.dropout(f, p, self.training), None
             return _LinearAddLayerNorm.apply(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7], x, next_norm.weight,
-                                             next_norm.bias, next_norm.eps, p)
+                                             next_norm.bias, next_norm.eps, p, sh[8])
         a = _linear(a, attn.out_proj.weight, attn.out_proj.bias, sh[2], sh[3])
         x, h = _add_norm(x, a, layer.norm2, p, self.training)
         f = F.dropout(F.relu(_linear(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5])), p, self.training)

@@ -227,6 +227,15 @@ int64_t g2048_relu_dropout_bwd_workspace_floats(int64_t T, int F);
 int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, float *workspace, int64_t T, int F,
                            float p_drop, void *stream);
 
+/* ---- policy network (update): Linear for tall-skinny activations ------------------------------------------ */
+
+/* y[T][N] = x[T][K] . weight[N][K]^T (+ bias[N]) - nn.Linear in bf16 with f32 accumulation (reference: every nn.Linear
+ * of nn.TransformerEncoderLayer, src/ppo/transformer_encoder.py:138-148, and the same product with weight^T for the
+ * input gradient).  x, weight, y bf16 with leading dimensions ldx, ldw, ldy (elements, multiples of 8); bias f32 or
+ * NULL; K and N multiples of 128; all base pointers 16-byte aligned. */
+int g2048_linear_bf16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const float *bias, void *y, int64_t ldy,
+                      int64_t T, int K, int N, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

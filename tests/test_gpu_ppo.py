@@ -526,6 +526,36 @@ def test_fused_linear_blocks_match_torch(dev):
             t.grad = None
         yr = torch.relu(F.linear(hh, w.to(torch.bfloat16), b.to(torch.bfloat16)))
         yr.backward(gy)
-        assert torch.equal(y, yr)
+        assert rel(y, yr) < 4e-3  # the wide case runs through g2048_linear_bf16 (f32 bias, one rounding)
         for name, g, t in zip(("h", "w", "b"), got, (hh, w, b)):
-            assert rel(g, t.grad) < 8e-3, (name, rel(g, t.grad))
+            assert rel(g, t.grad) < 2e-2, (name, rel(g, t.grad))  # units with z ~ 0 may land on either side of the ReLU
+
+
+def test_linear_bf16_matches_torch(dev):
+    """g2048_linear_bf16 (MFMA, weights streamed through LDS) vs an f32 reference: as close as hipBLASLt's bf16 GEMM,
+    ragged T, all (K, N) of the update, strided inputs/weights (views), with and without bias."""
+    import torch.nn.functional as F
+
+    from src.g2048 import native as nv
+
+    torch.manual_seed(13)
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    for T in (1, 31, 128, 129, 2048, 34816 + 5):
+        for K, N in ((256, 256), (256, 768), (256, 1024), (1024, 256), (768, 256), (128, 128), (512, 384)):
+            x = torch.randn(T, K, device=dev).to(torch.bfloat16)
+            w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+            b = torch.randn(N, device=dev)
+            ref = F.linear(x.float(), w.float(), b)
+            y = nv.linear_bf16(x, w, b)
+            assert y.shape == (T, N) and y.dtype == torch.bfloat16
+            assert rel(y, ref) < 4e-3, (T, K, N, rel(y, ref))
+            assert (y.float() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max() + 1e-2
+            y0 = nv.linear_bf16(x, w, None)
+            assert rel(y0, F.linear(x.float(), w.float())) < 4e-3
+    # views: a column slice of a wider activation, a row slice of a taller weight
+    xx = torch.randn(1000, 768, device=dev).to(torch.bfloat16)
+    ww = (torch.randn(768, 256, device=dev) / 16).to(torch.bfloat16)
+    y = nv.linear_bf16(xx[:, 256:512], ww[256:512], None)
+    assert rel(y, xx[:, 256:512].float() @ ww[256:512].float().t()) < 4e-3
+    with pytest.raises(nv.NativeError):
+        nv.linear_bf16(torch.zeros(8, 100, device=dev, dtype=torch.bfloat16), torch.zeros(128, 100, device=dev, dtype=torch.bfloat16))
