@@ -377,3 +377,120 @@ extern "C" int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, f
                        dbias);
     return done();
 }
+
+// ---- token embedding of packed boards (update) ---------------------------------------------------------------------------
+// x0[m][0] = cls;  x0[m][1 + c] = dropout(Wt[boards[m][c]] + pe[c])   (f32 [M][17][256]).
+// Reference: PPOAgent.forward's input_embedding (a bias-free Linear over the one-hot cell, src/ppo/ppo_agent.py:59-66,
+// 103-106) + PositionalEncoding2D + CLS concat (src/ppo/transformer_encoder.py:150-190).  In PyTorch that is a one-hot
+// expansion, a K = 31 GEMM, an add and a cat forward, and backward a [256 x 32768] x [32768 x 31] GEMM (146 us: the
+// reduction runs over every token of the minibatch), slice copies and a row sum for the CLS token.  Here the forward is
+// a gather and the backward a segmented sum: each wave adds its token rows into its own [32 classes][256] f32 image in
+// LDS (class 31 = the CLS token; plain read-modify-write, nobody else touches that image, so the order is fixed), the
+// four images of a workgroup are summed, and k_colsum_final adds the workgroups' partials.
+namespace {
+
+constexpr int EMB_D = 256, EMB_CLASSES = 32, EMB_SEQ = 17, EMB_BLOCKS = 256;
+
+__global__ void __launch_bounds__(256)
+k_embed_fwd(const uint8_t *__restrict__ boards, const float *__restrict__ wt, const float *__restrict__ pe,
+            const float *__restrict__ cls, float *__restrict__ x0, int64_t n_rows, float inv_keep, uint32_t thr, uint32_t s0,
+            uint32_t s1, const uint64_t *seed_state) {
+    mix_seed_state(seed_state, s0, s1);
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
+        const int64_t m = row / EMB_SEQ;
+        const int c = (int)(row - m * EMB_SEQ);
+        float4 v;
+        if (c == 0) {
+            v = reinterpret_cast<const float4 *>(cls)[lane];
+        } else {
+            const int e = boards[m * 16 + c - 1];
+            const float4 a = reinterpret_cast<const float4 *>(wt + (size_t)e * EMB_D)[lane];
+            const float4 b = reinterpret_cast<const float4 *>(pe + (size_t)(c - 1) * EMB_D)[lane];
+            v = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            if (thr) {
+                const uint64_t base = (uint64_t)row * EMB_D + 4 * lane;
+                v.x = keep_elem(s0, s1, thr, base + 0) ? v.x * inv_keep : 0.f;
+                v.y = keep_elem(s0, s1, thr, base + 1) ? v.y * inv_keep : 0.f;
+                v.z = keep_elem(s0, s1, thr, base + 2) ? v.z * inv_keep : 0.f;
+                v.w = keep_elem(s0, s1, thr, base + 3) ? v.w * inv_keep : 0.f;
+            }
+        }
+        reinterpret_cast<float4 *>(x0 + row * EMB_D)[lane] = v;
+    }
+}
+
+// partial[blockIdx][32][256]
+__global__ void __launch_bounds__(256)
+k_embed_bwd(const uint8_t *__restrict__ boards, const float *__restrict__ dx0, float *__restrict__ partial, int64_t n_rows,
+            float inv_keep, uint32_t thr, uint32_t s0, uint32_t s1, const uint64_t *seed_state) {
+    mix_seed_state(seed_state, s0, s1);
+    extern __shared__ __attribute__((aligned(16))) char emb_smem[];
+    float4 *img = reinterpret_cast<float4 *>(emb_smem);  // [4 waves][32 classes][64 lanes] float4
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4 *mine = img + (size_t)w * EMB_CLASSES * 64;
+    for (int k = 0; k < EMB_CLASSES; ++k) mine[k * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t per_block = (n_rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per_block, r1 = (r0 + per_block < n_rows) ? r0 + per_block : n_rows;
+    for (int64_t row = r0 + w; row < r1; row += 4) {
+        const int64_t m = row / EMB_SEQ;
+        const int c = (int)(row - m * EMB_SEQ);
+        const int k = c == 0 ? EMB_CLASSES - 1 : (boards[m * 16 + c - 1] & 31);
+        float4 g = reinterpret_cast<const float4 *>(dx0 + row * EMB_D)[lane];
+        if (thr && c != 0) {
+            const uint64_t base = (uint64_t)row * EMB_D + 4 * lane;
+            g.x = keep_elem(s0, s1, thr, base + 0) ? g.x * inv_keep : 0.f;
+            g.y = keep_elem(s0, s1, thr, base + 1) ? g.y * inv_keep : 0.f;
+            g.z = keep_elem(s0, s1, thr, base + 2) ? g.z * inv_keep : 0.f;
+            g.w = keep_elem(s0, s1, thr, base + 3) ? g.w * inv_keep : 0.f;
+        }
+        float4 a = mine[k * 64 + lane];
+        a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+        mine[k * 64 + lane] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < EMB_CLASSES * 64; i += 256) {
+        float4 s = img[i];
+        for (int ww = 1; ww < 4; ++ww) {
+            const float4 t = img[(size_t)ww * EMB_CLASSES * 64 + i];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        reinterpret_cast<float4 *>(partial + (size_t)blockIdx.x * EMB_CLASSES * EMB_D)[i] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int g2048_embed_fwd(const uint8_t *boards, const float *wt, const float *pe, const float *cls, float *x0, int64_t M,
+                               float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream) {
+    if (!boards || !wt || !pe || !cls || !x0 || M <= 0 || !(p_drop >= 0.f && p_drop < 1.f) ||
+        (((uintptr_t)wt | (uintptr_t)pe | (uintptr_t)cls | (uintptr_t)x0) & 15))
+        return G2048_EINVAL;
+    const int64_t n_rows = M * EMB_SEQ;
+    int64_t blocks = (n_rows + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_embed_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, boards, wt, pe, cls, x0, n_rows,
+                       1.0f / (1.0f - p_drop), (uint32_t)(p_drop * 16777216.0f), (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
+    return done();
+}
+
+extern "C" int64_t g2048_embed_bwd_workspace_floats(int64_t M) { return M <= 0 ? 0 : (int64_t)EMB_BLOCKS * EMB_CLASSES * EMB_D; }
+
+extern "C" int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, float *workspace, int64_t M, float p_drop,
+                               uint64_t seed, const uint64_t *seed_state, void *stream) {
+    if (!boards || !dx0 || !dwt_dcls || !workspace || M <= 0 || !(p_drop >= 0.f && p_drop < 1.f) ||
+        (((uintptr_t)dx0 | (uintptr_t)dwt_dcls | (uintptr_t)workspace) & 15))
+        return G2048_EINVAL;
+    static bool attr_set = false;  // benign race: idempotent
+    const int lds = 4 * EMB_CLASSES * EMB_D * (int)sizeof(float);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_embed_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int64_t n_rows = M * EMB_SEQ;
+    hipLaunchKernelGGL(k_embed_bwd, dim3(EMB_BLOCKS), dim3(256), lds, (hipStream_t)stream, boards, dx0, workspace, n_rows,
+                       1.0f / (1.0f - p_drop), (uint32_t)(p_drop * 16777216.0f), (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
+    hipLaunchKernelGGL(k_colsum_final, dim3(EMB_CLASSES * EMB_D / CF_COLS), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream, workspace,
+                       EMB_BLOCKS, EMB_CLASSES * EMB_D, dwt_dcls);
+    return done();
+}

@@ -50,6 +50,9 @@ SIGNATURES = {
     "g2048_ppo_loss": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp,
                        _vp, _vp],
     "g2048_linear_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
+    "g2048_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_embed_bwd_workspace_floats": [_i64],
+    "g2048_embed_bwd": [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_colsum_workspace_floats": [_i64, _i32],
     "g2048_colsum": [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp],
     "g2048_add_ln_bwd_workspace_floats": [_i64],
@@ -376,3 +379,18 @@ def linear_bf16(x2: torch.Tensor, weight: torch.Tensor, bias_f32=None, out=None)
                                     _dev(bias_f32, f32, N, "bias", optional=True), _dev(out, torch.bfloat16, T * N, "out"), N, T,
                                     K, N, _stream()), "g2048_linear_bf16")
     return out
+
+
+def embed_fwd(boards, wt, pe, cls, x0, p_drop: float = 0.0, seed: int = 0, seed_state: int = 0):
+    M = boards.numel() // 16
+    _check(load().g2048_embed_fwd(_dev(boards, u8, 16 * M, "boards"), _dev(wt, f32, 31 * 256, "wt"), _dev(pe, f32, 16 * 256, "pe"),
+                                  _dev(cls, f32, 256, "cls"), _dev(x0, f32, M * 17 * 256, "x0"), M, float(p_drop), int(seed),
+                                  seed_state or None, _stream()), "g2048_embed_fwd")
+
+
+def embed_bwd(boards, dx0, dwt_dcls, p_drop: float = 0.0, seed: int = 0, seed_state: int = 0):
+    M = boards.numel() // 16
+    ws = torch.empty(load().g2048_embed_bwd_workspace_floats(M), dtype=f32, device=dx0.device)
+    _check(load().g2048_embed_bwd(_dev(boards, u8, 16 * M, "boards"), _dev(dx0, f32, M * 17 * 256, "dx0"),
+                                  _dev(dwt_dcls, f32, 32 * 256, "dwt_dcls"), ws.data_ptr(), M, float(p_drop), int(seed),
+                                  seed_state or None, _stream()), "g2048_embed_bwd")

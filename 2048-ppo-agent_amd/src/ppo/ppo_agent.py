@@ -105,6 +105,9 @@ class PPOAgent(_ActorCritic):
         return self.input_embedding(observations)
 
     def features(self, observations):
+        w = self.input_embedding.weight
+        if self.transformer.embed_boards_ok(observations, w):
+            return self.transformer.forward_boards(observations, w, reduction=self.reduction)
         return self.transformer(self.embed(observations), reduction=self.reduction)
 
 

@@ -434,6 +434,37 @@ def _add_norm(x: torch.Tensor, a, norm: nn.LayerNorm, p: float, training: bool):
     return x, F.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)
 
 
+class _EmbedBoards(torch.autograd.Function):
+    """Packed boards u8 [M, 16] -> token matrix f32 [M, 17, 256]: CLS row + dropout(embedding + positional code), one
+    gather kernel (``g2048_embed_fwd``); the backward is a segmented sum by cell value (``g2048_embed_bwd``) instead of
+    a one-hot^T x gradient GEMM whose reduction runs over every token of the minibatch.
+    emb_weight: the bias-free input Linear's weight [256, 31]; pe f32 [16, 256]; cls [1, 1, 256]."""
+
+    @staticmethod
+    def forward(ctx, boards, emb_weight, pe, cls, p_drop):
+        from ..g2048 import native as nv
+
+        boards = boards.contiguous()
+        M = boards.shape[0]
+        wt = emb_weight.detach().float().t().contiguous()
+        x0 = torch.empty((M, 17, 256), dtype=torch.float32, device=boards.device)
+        seed = _seed_pair(x0, p_drop)
+        nv.embed_fwd(boards, wt, pe, cls.detach().float().reshape(256).contiguous(), x0, p_drop, *seed)
+        ctx.save_for_backward(boards)
+        ctx.meta = (p_drop, seed, emb_weight.dtype, cls.dtype)
+        return x0
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..g2048 import native as nv
+
+        (boards,) = ctx.saved_tensors
+        p_drop, seed, w_dtype, c_dtype = ctx.meta
+        out = torch.empty((32, 256), dtype=torch.float32, device=g.device)
+        nv.embed_bwd(boards, g.contiguous(), out, p_drop, *seed)
+        return None, out[:31].t().to(w_dtype), None, out[31].view(1, 1, 256).to(c_dtype), None
+
+
 def _fused_attention_ok(t: torch.Tensor, S: int, head_dim: int) -> bool:
     return (t.is_cuda and t.dtype == torch.bfloat16 and S == 17 and head_dim == 32 and torch.is_grad_enabled()
             and t.requires_grad)
@@ -581,6 +612,23 @@ class TransformerEncoder(nn.Module):
             raise ValueError(f"reduction must be 'mean' or 'cls', got {reduction}")
         x = self.positional_encoding.forward_flat(src)
         x = torch.cat([_ExpandRows.apply(self.cls_token.to(x.dtype), x.shape[0]), x], dim=1)
+        return self.encode(x, reduction)
+
+    def embed_boards_ok(self, boards: torch.Tensor, emb_weight: torch.Tensor) -> bool:
+        """The update path with packed boards at the reference shape: ``_EmbedBoards`` applies."""
+        return (boards.dtype == torch.uint8 and boards.dim() == 2 and boards.shape[1] == 16 and self.d_model == 256
+                and tuple(emb_weight.shape) == (256, 31) and _train_bf16(boards, emb_weight))
+
+    def forward_boards(self, boards: torch.Tensor, emb_weight: torch.Tensor, reduction: str = "mean") -> torch.Tensor:
+        """Packed boards u8 [B, 16] -> [B, d_model] (embedding, positions, CLS and the encoder layers)."""
+        pe = self.positional_encoding.flat_table().float().contiguous()
+        p = self.positional_encoding.dropout.p if self.training else 0.0
+        return self.encode(_EmbedBoards.apply(boards, emb_weight, pe, self.cls_token, p), reduction)
+
+    def encode(self, x: torch.Tensor, reduction: str = "mean") -> torch.Tensor:
+        """[B, 17, d_model] tokens (CLS first, positions added) through the encoder layers -> [B, d_model]."""
+        if reduction not in ["mean", "cls"]:
+            raise ValueError(f"reduction must be 'mean' or 'cls', got {reduction}")
         layers = self.encoder.layers
         last = len(layers) - 1
         sh = self._bf16_weights(x)

@@ -236,6 +236,21 @@ int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias
 int g2048_linear_bf16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const float *bias, void *y, int64_t ldy,
                       int64_t T, int K, int N, void *stream);
 
+/* ---- policy network (update): token embedding of packed boards ---------------------------------------------- */
+
+/* x0[m][0] = cls, x0[m][1 + c] = dropout(wt[boards[m][c]] + pe[c]): the bias-free input Linear over the one-hot cell (wt =
+ * input_embedding.weight^T, f32 [31][256]), the 2-D positional code (pe f32 [16][256]) and the CLS concat
+ * (reference: src/ppo/ppo_agent.py:59-66,103-106; src/ppo/transformer_encoder.py:150-190).  boards u8 [M][16] with
+ * cells <= 30, x0 f32 [M][17][256].  The positional encoding's dropout (p_drop; seed, seed_state as for g2048_attn_fwd)
+ * applies to the 16 board tokens, not to the CLS row. */
+int g2048_embed_fwd(const uint8_t *boards, const float *wt, const float *pe, const float *cls, float *x0, int64_t M,
+                    float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
+/* dwt_dcls f32 [32][256]: rows 0..30 = gradient of wt (sum of dx0 rows by cell value), row 31 = gradient of cls; fixed
+ * summation order.  dx0 f32 [M][17][256]; workspace: g2048_embed_bwd_workspace_floats(M) floats. */
+int64_t g2048_embed_bwd_workspace_floats(int64_t M);
+int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, float *workspace, int64_t M, float p_drop,
+                    uint64_t seed, const uint64_t *seed_state, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -559,3 +559,49 @@ def test_linear_bf16_matches_torch(dev):
     assert rel(y, xx[:, 256:512].float() @ ww[256:512].float().t()) < 4e-3
     with pytest.raises(nv.NativeError):
         nv.linear_bf16(torch.zeros(8, 100, device=dev, dtype=torch.bfloat16), torch.zeros(128, 100, device=dev, dtype=torch.bfloat16))
+
+
+def test_embed_boards_matches_torch(dev):
+    """g2048_embed_fwd/bwd (gather + segmented sum) vs one-hot Linear + positional add + CLS concat in PyTorch: tokens and
+    the gradients of the embedding weight and the CLS token; with dropout only board tokens are dropped, the backward
+    reuses the mask, and the sums are bit-reproducible."""
+    from src.ppo.transformer_encoder import _EmbedBoards
+
+    torch.manual_seed(17)
+    for M in (1, 5, 2048, 2049):
+        boards = torch.randint(0, 31, (M, 16), device=dev, dtype=torch.uint8)
+        w = torch.randn(256, 31, device=dev, requires_grad=True)
+        pe = torch.randn(16, 256, device=dev)
+        cls = torch.randn(1, 1, 256, device=dev, requires_grad=True)
+        g = torch.randn(M, 17, 256, device=dev)
+        x0 = _EmbedBoards.apply(boards, w, pe, cls, 0.0)
+        x0.backward(g)
+        got = (w.grad.clone(), cls.grad.clone())
+        w.grad = cls.grad = None
+        onehot = torch.nn.functional.one_hot(boards.long(), 31).float()
+        ref = torch.cat([cls.expand(M, -1, -1), onehot @ w.t() + pe], dim=1)
+        ref.backward(g)
+        assert torch.equal(x0, ref.detach()) or torch.allclose(x0, ref, atol=1e-6)
+        assert torch.allclose(got[0], w.grad, rtol=1e-4, atol=1e-3 * max(1.0, M ** 0.5))
+        assert torch.allclose(got[1], cls.grad, rtol=1e-4, atol=1e-3 * max(1.0, M ** 0.5))
+        again = _EmbedBoards.apply(boards, w, pe, cls, 0.0)
+        w.grad = cls.grad = None
+        again.backward(g)
+        assert torch.equal(w.grad, got[0]) and torch.equal(cls.grad, got[1])
+        w.grad = cls.grad = None
+    boards = torch.randint(0, 31, (4096, 16), device=dev, dtype=torch.uint8)
+    w = torch.randn(256, 31, device=dev, requires_grad=True)
+    pe = torch.zeros(16, 256, device=dev)
+    cls = torch.randn(1, 1, 256, device=dev, requires_grad=True)
+    x0 = _EmbedBoards.apply(boards, w, pe, cls, 0.1)
+    full = _EmbedBoards.apply(boards, w, pe, cls, 0.0)
+    assert torch.equal(x0[:, 0], full[:, 0])  # CLS row is never dropped
+    kept = x0[:, 1:] != 0
+    assert abs(kept.float().mean().item() - 0.9) < 2e-3
+    assert torch.allclose(x0[:, 1:][kept], (full[:, 1:] / 0.9)[kept], rtol=1e-6)
+    x0.sum().backward()
+    counts = torch.zeros(31, device=dev)
+    for e in range(31):
+        counts[e] = (kept & (boards == e).unsqueeze(-1)).sum() / 256.0
+    assert torch.allclose(w.grad.mean(0), counts / 0.9, rtol=1e-2, atol=1e-2)  # masked the same way as the forward
+    assert torch.allclose(cls.grad.reshape(-1), torch.full((256,), 4096.0, device=dev))
