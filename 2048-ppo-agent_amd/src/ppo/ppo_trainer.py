@@ -429,8 +429,15 @@ class PPOTrainer:
                     sample = dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret)
                     gkey = (batch_size, obs.dtype, tuple(obs.shape[1:]))
                     if gkey not in self._graphs:
-                        self._graphs[gkey] = _GraphedFwdBwd(self, batch_size, sample)
-                    graphed = self._graphs[gkey]
+                        try:
+                            self._graphs[gkey] = _GraphedFwdBwd(self, batch_size, sample)
+                        except Exception as e:  # the eager path computes the same thing, only slower: never lose a run
+                            logger.warning("hipGraph capture of the update failed (%s); continuing in eager mode", e)
+                            self.use_hip_graph = False
+                            self._graphs.clear()
+                            self.optimizer.zero_grad(set_to_none=True)
+                    graphed = self._graphs.get(gkey)
+                if graphed is not None:
                     stats, kl = graphed.run(sample)
                 else:
                     stats, kl = self._loss_backward(obs, actions, masks, old_lp, adv, ret)
