@@ -17,6 +17,13 @@
 //
 // Numerics mirror torch.autocast(bf16): GEMM inputs rounded to bf16, f32 accumulation, f32 residual stream,
 // f32 LayerNorm / softmax statistics.
+//
+// Two-kernel form (when the caller passes a workspace).  Only the CLS row of the LAST layer is read by the "cls"
+// reduction, yet that layer's Q / out-proj / feed-forward weights (1.26 MB) would be streamed for 7 useful tokens per
+// workgroup.  MODE_HEAD runs layers 0..L-2 as described, then only LayerNorm + the K/V projections of layer L-1, and
+// parks K, V (bf16, 17 KB per board) and the CLS residual row in HBM.  MODE_TAIL batches the CLS tokens of 128 boards
+// per workgroup (one board per lane) through the rest of layer L-1: Q projection, attention of that single query
+// over its board's 17 keys in-lane (K/V from HBM), out-proj, feed-forward - the same code with 18x fewer workgroups.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -216,28 +223,41 @@ __device__ __forceinline__ void layer_norm(const f32x16 r[8], const float *gamma
         }
 }
 
+constexpr int MODE_FULL = 0, MODE_HEAD = 1, MODE_TAIL = 2;
+// HBM workspace of the two-kernel form, per board: K and V of the last layer as [head][key][lane half][16] bf16 (the 16
+// values a lane half holds for one (token, head) are contiguous), then the CLS residual row (256 f32).
+constexpr int64_t KV_ELEMS = (int64_t)NH * SEQ * HD;  // per board, per K or V
+
+template <int MODE>
 __global__ void __launch_bounds__(THREADS, 1)
 k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, const float *__restrict__ cls,
           const __bf16 *__restrict__ wblob, const float *__restrict__ pblob, int n_layers,
-          float *__restrict__ features, int64_t B) {
+          float *__restrict__ features, int64_t B, __bf16 *__restrict__ ws_k, __bf16 *__restrict__ ws_v,
+          float *__restrict__ ws_r) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lds &L = *reinterpret_cast<Lds *>(smem);
     LdsAttn &A = L.act.a;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int64_t board0 = (int64_t)blockIdx.x * NBOARD;
+    const int64_t board0 = (int64_t)blockIdx.x * (MODE == MODE_TAIL ? NTOK : NBOARD);
     char *const wq = L.w, *const wk = L.w + TILE, *const wv = L.w + 2 * TILE;
     LaneOff lo;
     lane_offsets(lo, r, h, w, lane);
 
-    // ---- this lane's token
+    // ---- this lane's token.  MODE_TAIL: token = the CLS token of board board0 + tok.
     const int tok = 32 * w + r;                     // 0..127 inside the tile
-    const int tb = tok / SEQ, tc = tok - tb * SEQ;  // board in tile, position (0 = CLS)
-    const bool tok_valid = tb < NBOARD && board0 + tb < B;
-    const bool tok_real = tb < NBOARD;
+    const int tb = MODE == MODE_TAIL ? tok : tok / SEQ;         // board in tile
+    const int tc = MODE == MODE_TAIL ? 0 : tok - tb * SEQ;      // position (0 = CLS)
+    const bool tok_real = MODE == MODE_TAIL ? true : tb < NBOARD;
+    const bool tok_valid = tok_real && board0 + tb < B;
+    const int64_t my_board = tok_valid ? board0 + tb : (B - 1);  // clamped: loads stay in bounds, stores are guarded
 
-    // ---- embedding + positional code + CLS: R^T[f][tok]
+    // ---- embedding + positional code + CLS: R^T[f][tok]   (MODE_TAIL: the parked CLS residual row)
     f32x16 R[8];
-    {
+    if (MODE == MODE_TAIL) {
+        const float *src = ws_r + my_board * D;
+        for (int j = 0; j < 8; ++j)
+            for (int i = 0; i < 16; ++i) R[j][i] = src[32 * j + rowof(i, h)];
+    } else {
         const float *src = cls;
         if (tok_valid && tc != 0) src = table + ((size_t)(tc - 1) * 31 + boards[(board0 + tb) * 16 + (tc - 1)]) * D;
         const float keep = tok_valid ? 1.0f : 0.0f;
@@ -246,13 +266,15 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
     }
 
 #pragma nounroll
-    for (int layer = 0; layer < n_layers; ++layer) {
+    for (int layer = (MODE == MODE_TAIL ? n_layers - 1 : 0); layer < (MODE == MODE_HEAD ? n_layers - 1 : n_layers); ++layer) {
         const __bf16 *W = wblob + (size_t)layer * W_LAYER;
         const float *P = pblob + (size_t)layer * P_LAYER;
         auto dma_qkv = [&](int hd) {
             dma_tile<32>(wq, W + WO_QKV + (size_t)(0 * D + HD * hd) * D, D, HD, lo, w);
-            dma_tile<32>(wk, W + WO_QKV + (size_t)(1 * D + HD * hd) * D, D, HD, lo, w);
-            dma_tile<32>(wv, W + WO_QKV + (size_t)(2 * D + HD * hd) * D, D, HD, lo, w);
+            if (MODE != MODE_TAIL) {
+                dma_tile<32>(wk, W + WO_QKV + (size_t)(1 * D + HD * hd) * D, D, HD, lo, w);
+                dma_tile<32>(wv, W + WO_QKV + (size_t)(2 * D + HD * hd) * D, D, HD, lo, w);
+            }
         };
         auto wo_of = [&](int hd) -> char * { return L.w + (3 + (hd & 1)) * TILE; };  // double-buffered
         auto dma_wo = [&](int hd) { dma_tile<4>(wo_of(hd), W + WO_O + HD * hd, D, D, lo, w); };
@@ -274,6 +296,62 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
 
 #pragma nounroll
         for (int hd = 0; hd < NH; ++hd) {
+            if (MODE == MODE_TAIL) {
+                // Q^T [32 d][32 boards] of the CLS tokens; the single query of a board attends to that board's 17 keys
+                // in-lane: this lane half holds 16 of the 32 head dims (d = rowof(i, h)), exactly the 16 contiguous
+                // values MODE_HEAD parked per (board, head, key, half)
+                const f32x16 zero = {0};
+                f32x16 qa = gemm_tile<32, 16>(wq, lo, 0, xn, zero);
+                pipe_mfma<16>();
+                for (int i = 0; i < 16; ++i) qa[i] += L.bias[0 * D + HD * hd + rowof(i, h)];
+                const size_t off = (size_t)my_board * KV_ELEMS + (size_t)hd * SEQ * HD + 16 * h;
+                float sc[SEQ], m = -3.0e38f;
+                for (int key = 0; key < SEQ; ++key) {
+                    const bf16x8 k0 = *reinterpret_cast<const bf16x8 *>(ws_k + off + key * HD);
+                    const bf16x8 k1 = *reinterpret_cast<const bf16x8 *>(ws_k + off + key * HD + 8);
+                    float d = 0.f;
+                    // q is rounded to bf16 like the operand of the full kernel's K Q^T product
+                    for (int i = 0; i < 8; ++i) d += (float)(__bf16)qa[i] * (float)k0[i] + (float)(__bf16)qa[8 + i] * (float)k1[i];
+                    d += __shfl_xor(d, 32);
+                    sc[key] = d * 0.17677669529663687f;
+                    m = fmaxf(m, sc[key]);
+                }
+                float sum = 0.f;
+                for (int key = 0; key < SEQ; ++key) {
+                    sc[key] = __expf(sc[key] - m);
+                    sum += sc[key];
+                }
+                const float inv = 1.0f / sum;
+                float o[16];
+                for (int i = 0; i < 16; ++i) o[i] = 0.f;
+                for (int key = 0; key < SEQ; ++key) {
+                    const bf16x8 v0 = *reinterpret_cast<const bf16x8 *>(ws_v + off + key * HD);
+                    const bf16x8 v1 = *reinterpret_cast<const bf16x8 *>(ws_v + off + key * HD + 8);
+                    const float p = (float)(__bf16)(sc[key] * inv);  // bf16 probabilities, as the MFMA operand would be
+                    for (int i = 0; i < 8; ++i) {
+                        o[i] += p * (float)v0[i];
+                        o[8 + i] += p * (float)v1[i];
+                    }
+                }
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 ov;
+                    for (int q = 0; q < 4; ++q) ov[q] = (__bf16)o[4 * g + q];
+                    *reinterpret_cast<bf16x4 *>(A.o + tok * ST32 + 2 * (8 * g + 4 * h)) = ov;
+                }
+                __syncthreads();  // O visible; this head's Q tile is free
+                if (hd + 1 < NH) {
+                    dma_qkv(hd + 1);
+                    dma_wo(hd + 1);
+                }
+                bf16x8 of[2];
+                for (int ks = 0; ks < 2; ++ks) of[ks] = load_p(A.o + tok * ST32, ks, h);
+                const char *wo = wo_of(hd);
+                for (int j = 0; j < 8; ++j) R[j] = gemm_tile<4, 2>(wo, lo, j, of, R[j]);
+                pipe_mfma<16>();
+                dma_wait_all();
+                __syncthreads();  // next head's tiles landed; O of this head is free
+                continue;
+            }
             // Q^T, K^T, V^T [32 d][32 tok] for this wave's tokens
             const f32x16 zero = {0};
             f32x16 qa = gemm_tile<32, 16>(wq, lo, 0, xn, zero);
@@ -385,7 +463,58 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
             for (int i = 0; i < 16; ++i) R[j][i] += P[PO_B2 + 32 * j + rowof(i, h)];
     }
 
-    // ---- CLS rows out
+
+    if (MODE == MODE_HEAD) {
+        // ---- last layer, K/V only: LayerNorm, K^T and V^T of every head -> HBM, CLS residual row -> HBM
+        const __bf16 *W = wblob + (size_t)(n_layers - 1) * W_LAYER;
+        const float *P = pblob + (size_t)(n_layers - 1) * P_LAYER;
+        auto dma_kv = [&](int hd) {
+            dma_tile<32>(wk, W + WO_QKV + (size_t)(1 * D + HD * hd) * D, D, HD, lo, w);
+            dma_tile<32>(wv, W + WO_QKV + (size_t)(2 * D + HD * hd) * D, D, HD, lo, w);
+        };
+        __syncthreads();  // previous layer's feed-forward tiles are no longer read
+        dma_kv(0);
+        stage_f32(L.gamma, P + PO_LN1G, D, tid);
+        stage_f32(L.beta, P + PO_LN1B, D, tid);
+        stage_f32(L.bias, P + PO_BQKV, 3 * D, tid);
+        dma_wait_all();
+        __syncthreads();
+        if (tok_valid && tc == 0) {
+            float *dst = ws_r + (board0 + tb) * D;
+            for (int j = 0; j < 8; ++j)
+                for (int i = 0; i < 16; ++i) dst[32 * j + rowof(i, h)] = R[j][i];
+        }
+        bf16x8 xn[16];
+        layer_norm(R, L.gamma, L.beta, h, xn);
+#pragma nounroll
+        for (int hd = 0; hd < NH; ++hd) {
+            const f32x16 zero = {0};
+            f32x16 ka = gemm_tile<32, 16>(wk, lo, 0, xn, zero);
+            f32x16 va = gemm_tile<32, 16>(wv, lo, 0, xn, zero);
+            pipe_mfma<32>();
+            if (tok_valid) {
+                const size_t off = (size_t)(board0 + tb) * KV_ELEMS + ((size_t)hd * SEQ + tc) * HD + 16 * h;
+                bf16x8 k0, k1, v0, v1;
+                for (int i = 0; i < 8; ++i) {
+                    k0[i] = (__bf16)(ka[i] + L.bias[1 * D + HD * hd + rowof(i, h)]);
+                    k1[i] = (__bf16)(ka[8 + i] + L.bias[1 * D + HD * hd + rowof(8 + i, h)]);
+                    v0[i] = (__bf16)(va[i] + L.bias[2 * D + HD * hd + rowof(i, h)]);
+                    v1[i] = (__bf16)(va[8 + i] + L.bias[2 * D + HD * hd + rowof(8 + i, h)]);
+                }
+                *reinterpret_cast<bf16x8 *>(ws_k + off) = k0;
+                *reinterpret_cast<bf16x8 *>(ws_k + off + 8) = k1;
+                *reinterpret_cast<bf16x8 *>(ws_v + off) = v0;
+                *reinterpret_cast<bf16x8 *>(ws_v + off + 8) = v1;
+            }
+            __syncthreads();  // this head's K/V weight tiles are free
+            if (hd + 1 < NH) dma_kv(hd + 1);
+            dma_wait_all();
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- CLS rows out (MODE_TAIL: every lane's token is one)
     if (tok_valid && tc == 0) {
         float *dst = features + (board0 + tb) * D;
         for (int j = 0; j < 8; ++j)
@@ -395,16 +524,25 @@ k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, c
 
 }  // namespace
 
+extern "C" int64_t g2048_policy_encoder_workspace_bytes(int64_t B) {
+    return B <= 0 ? 0 : B * (2 * KV_ELEMS * (int64_t)sizeof(__bf16) + D * (int64_t)sizeof(float));
+}
+
 extern "C" int g2048_policy_encoder(const uint8_t *boards, const float *embed_table, const float *cls_token,
                                     const void *weights_bf16, const float *params_f32, int n_layers,
-                                    float *features, int64_t B, void *stream) {
+                                    float *features, int64_t B, void *workspace, void *stream) {
     if (!boards || !embed_table || !cls_token || !weights_bf16 || !params_f32 || !features || n_layers < 1 || B <= 0)
         return G2048_EINVAL;
-    if (((uintptr_t)weights_bf16 & 15) || ((uintptr_t)params_f32 & 15) || ((uintptr_t)embed_table & 3))
+    if (((uintptr_t)weights_bf16 & 15) || ((uintptr_t)params_f32 & 15) || ((uintptr_t)embed_table & 3) ||
+        ((uintptr_t)workspace & 15))
         return G2048_EINVAL;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_encoder),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_encoder<MODE_FULL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_encoder<MODE_HEAD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_encoder<MODE_TAIL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
         attr_set = true;
     }
@@ -416,9 +554,19 @@ extern "C" int g2048_policy_encoder(const uint8_t *boards, const float *embed_ta
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int));
         }
     }
+    const __bf16 *wb = reinterpret_cast<const __bf16 *>(weights_bf16);
     const unsigned blocks = (unsigned)((B + NBOARD - 1) / NBOARD);
-    hipLaunchKernelGGL(k_encoder, dim3(blocks), dim3(THREADS), sizeof(Lds), (hipStream_t)stream, boards, embed_table,
-                       cls_token, reinterpret_cast<const __bf16 *>(weights_bf16), params_f32, n_layers, features, B);
+    if (!workspace) {
+        hipLaunchKernelGGL(k_encoder<MODE_FULL>, dim3(blocks), dim3(THREADS), sizeof(Lds), (hipStream_t)stream, boards, embed_table,
+                           cls_token, wb, params_f32, n_layers, features, B, (__bf16 *)nullptr, (__bf16 *)nullptr, (float *)nullptr);
+    } else {
+        __bf16 *ws_k = reinterpret_cast<__bf16 *>(workspace), *ws_v = ws_k + B * KV_ELEMS;
+        float *ws_r = reinterpret_cast<float *>(ws_v + B * KV_ELEMS);
+        hipLaunchKernelGGL(k_encoder<MODE_HEAD>, dim3(blocks), dim3(THREADS), sizeof(Lds), (hipStream_t)stream, boards, embed_table,
+                           cls_token, wb, params_f32, n_layers, features, B, ws_k, ws_v, ws_r);
+        hipLaunchKernelGGL(k_encoder<MODE_TAIL>, dim3((unsigned)((B + NTOK - 1) / NTOK)), dim3(THREADS), sizeof(Lds), (hipStream_t)stream,
+                           boards, embed_table, cls_token, wb, params_f32, n_layers, features, B, ws_k, ws_v, ws_r);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }

@@ -41,7 +41,8 @@ SIGNATURES = {
     "g2048_gae_tb": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _dbl, _dbl, _vp],
     "g2048_gae_flat": [_vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp],
     "g2048_compact": [_vp] * 14 + [_i64, _i64, _vp],
-    "g2048_policy_encoder": [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp],
+    "g2048_policy_encoder_workspace_bytes": [_i64],
+    "g2048_policy_encoder": [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp],
     "g2048_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, C.c_float,
                        C.c_float, C.c_uint64, _vp, _vp],
     "g2048_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,
@@ -84,7 +85,7 @@ def load() -> C.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
-            fn.restype = C.c_int64 if name.endswith("_workspace_floats") else C.c_int
+            fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_workspace_bytes")) else C.c_int
         if lib.g2048_abi_version() != 1:
             raise NativeError("libg2048.so ABI version mismatch")
         _lib = lib
@@ -255,13 +256,23 @@ def compact(tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, ep_len, offsets,
         _stream()), "g2048_compact")
 
 
-def policy_encoder(boards, embed_table, cls_token, weights_bf16, params_f32, n_layers: int, features):
+def policy_encoder_workspace_bytes(B: int) -> int:
+    return int(load().g2048_policy_encoder_workspace_bytes(B))
+
+
+def policy_encoder(boards, embed_table, cls_token, weights_bf16, params_f32, n_layers: int, features, workspace=None):
+    """workspace: None (single kernel) or a uint8 device tensor of policy_encoder_workspace_bytes(B) bytes (the last
+    layer then runs CLS-only in a second kernel)."""
     B = boards.numel() // 16
+    if workspace is not None:
+        need = policy_encoder_workspace_bytes(B)
+        if not workspace.is_cuda or workspace.dtype != u8 or workspace.numel() < need or not workspace.is_contiguous():
+            raise NativeError(f"workspace: expected a contiguous uint8 device tensor of >= {need} bytes")
     _check(load().g2048_policy_encoder(
         _dev(boards, u8, 16 * B, "boards"), _dev(embed_table, f32, 16 * 31 * 256, "embed_table"),
         _dev(cls_token, f32, 256, "cls_token"), _dev(weights_bf16, torch.bfloat16, n_layers * 786432, "weights_bf16"),
         _dev(params_f32, f32, n_layers * 3328, "params_f32"), n_layers, _dev(features, f32, 256 * B, "features"), B,
-        _stream()), "g2048_policy_encoder")
+        None if workspace is None else workspace.data_ptr(), _stream()), "g2048_policy_encoder")
 
 
 def attn_fwd(q_ptr: int, k_ptr: int, v_ptr: int, o, lse, B: int, H: int, Sq: int, strides, scale: float, p_drop: float,

@@ -60,11 +60,27 @@ class FusedPolicy:
         self.params = torch.cat([x.detach().reshape(-1).float() for x in p]).contiguous()
         self.n_layers = len(t.encoder.layers)
 
+    # from this many boards on, the last layer runs CLS-only in a second kernel (g2048_policy_encoder with a workspace):
+    # below it the second kernel's fixed ~0.1 ms outweighs what the first one saves
+    SPLIT_MIN_BOARDS = 4096
+
+    def _workspace(self, B: int, device) -> torch.Tensor:
+        need = nv.policy_encoder_workspace_bytes(B)
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return ws
+
     @torch.no_grad()
-    def features(self, boards: torch.Tensor) -> torch.Tensor:
+    def features(self, boards: torch.Tensor, split=None) -> torch.Tensor:
+        """boards u8 [B, 16] -> CLS features f32 [B, 256].  ``split``: force (True) / forbid (False) the two-kernel form."""
         boards = boards.contiguous()
-        out = torch.empty((boards.shape[0], 256), dtype=torch.float32, device=boards.device)
-        nv.policy_encoder(boards, self.table, self.cls, self.weights, self.params, self.n_layers, out)
+        B = boards.shape[0]
+        out = torch.empty((B, 256), dtype=torch.float32, device=boards.device)
+        if split is None:
+            split = B >= self.SPLIT_MIN_BOARDS
+        ws = self._workspace(B, boards.device) if split else None
+        nv.policy_encoder(boards, self.table, self.cls, self.weights, self.params, self.n_layers, out, ws)
         return out
 
     @torch.no_grad()

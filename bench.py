@@ -111,11 +111,16 @@ def policy_encoder_roofline(agent, dev, boards: int, launches: int = 5):
     torch.cuda.synchronize()
     ms = start.elapsed_time(end) / launches
     layers = fp.n_layers
-    flop_per_board = layers * (17 * 2 * (256 * 768 + 256 * 256 + 2 * 256 * 1024) + 8 * 2 * 2 * 17 * 17 * 32)
+    # algorithmic = what the "cls" reduction needs: every token through layers 0..L-2; in the last layer K/V of every
+    # token but Q, attention, out-proj and feed-forward of the CLS token only (the kernel pair computes exactly that)
+    full = 17 * 2 * (256 * 768 + 256 * 256 + 2 * 256 * 1024) + 8 * 2 * 2 * 17 * 17 * 32
+    last = 17 * 2 * 256 * 512 + 2 * (256 * 256 + 256 * 256 + 2 * 256 * 1024) + 8 * 2 * 2 * 17 * 32
+    flop_per_board = (layers - 1) * full + last
     tf = flop_per_board * boards / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-            "kernel": "k_encoder (g2048_policy_encoder)", "boards_per_launch": boards, "launch_ms": round(ms, 3),
-            "algorithmic_flop_per_board": flop_per_board, "dtype": "bf16 in / f32 accumulate"}
+            "kernel": "k_encoder<HEAD> + k_encoder<TAIL> (g2048_policy_encoder, CLS-only last layer)",
+            "boards_per_launch": boards, "launch_ms": round(ms, 3), "algorithmic_flop_per_board": flop_per_board,
+            "flop_per_board_all_tokens_all_layers": layers * full, "dtype": "bf16 in / f32 accumulate"}
 
 
 class _TimedPolicyStep:

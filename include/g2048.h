@@ -142,10 +142,16 @@ int g2048_compact(const uint8_t *tr_boards, const uint8_t *tr_meta, const float 
  *   weights_bf16, per layer: in_proj_weight[768][256] | out_proj.weight[256][256] | linear1.weight[1024][256] |
  *                            linear2.weight[256][1024]                                     (bf16, 16-byte aligned)
  *   params_f32,  per layer: norm1.weight[256] | norm1.bias[256] | in_proj_bias[768] | out_proj.bias[256] |
- *                            norm2.weight[256] | norm2.bias[256] | linear1.bias[1024] | linear2.bias[256] */
+ *                            norm2.weight[256] | norm2.bias[256] | linear1.bias[1024] | linear2.bias[256]
+ *
+ * workspace: NULL = one kernel carries every token through every layer.  Otherwise
+ * g2048_policy_encoder_workspace_bytes(B) bytes (16-byte aligned): the last layer is split - a first kernel parks that
+ * layer's K/V and the CLS residual row there, a second one batches the CLS tokens of 128 boards per workgroup through the
+ * rest of it (only the CLS row of the last layer is read by the "cls" reduction).  Same result up to summation order. */
+int64_t g2048_policy_encoder_workspace_bytes(int64_t B);
 int g2048_policy_encoder(const uint8_t *boards, const float *embed_table, const float *cls_token,
                          const void *weights_bf16, const float *params_f32, int n_layers, float *features,
-                         int64_t B, void *stream);
+                         int64_t B, void *workspace, void *stream);
 
 /* ---- policy network (update): attention for 17-token sequences ------------------------------------- */
 

@@ -167,18 +167,21 @@ def test_fused_encoder_matches_autocast_forward(dev):
                     p.add_(torch.randn_like(p) * 0.05)  # non-trivial biases / LayerNorm affine
         assert supports(agent)
         fp = FusedPolicy(agent)
-        for B in (1, 7, 8, 100, 4097):
+        for B in (1, 7, 8, 100, 129, 4097):
             boards = torch.randint(0, 14, (B, 16), dtype=torch.uint8, device=dev)
             with torch.no_grad():
                 ref32 = agent.features(boards)
                 with torch.autocast("cuda", dtype=torch.bfloat16):
                     ref16 = agent.features(boards).float()
                     l16, v16 = agent(boards)
-            got = fp.features(boards)
-            assert torch.isfinite(got).all()
-            err, base = (got - ref16).abs().mean().item(), (ref16 - ref32).abs().mean().item()
-            assert err < 1.5 * base + 1e-4, (layers, B, err, base)
-            assert (got - ref32).abs().max().item() < 0.05 * max(1.0, ref32.abs().max().item())
+            for split in (False, True):  # one kernel / CLS-only last layer in a second kernel
+                got = fp.features(boards, split=split)
+                assert torch.isfinite(got).all()
+                err, base = (got - ref16).abs().mean().item(), (ref16 - ref32).abs().mean().item()
+                assert err < 1.5 * base + 1e-4, (layers, B, split, err, base)
+                assert (got - ref32).abs().max().item() < 0.05 * max(1.0, ref32.abs().max().item())
+            one, two = fp.features(boards, split=False), fp.features(boards, split=True)
+            assert (one - two).abs().max().item() < 0.02 * max(1.0, one.abs().max().item())
             logits, values = fp(boards)
             assert (logits - l16.float()).abs().max().item() < 0.05 and (values - v16.float().flatten()).abs().max().item() < 0.05
     assert not supports(PPOAgent(d_model=128, nhead=8, num_layers=1, dim_feedforward=256).to(dev))

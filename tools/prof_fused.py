@@ -9,7 +9,10 @@ agent = PPOAgent(**bench.MODEL_CFG).to(dev).eval()
 fp = FusedPolicy(agent)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 boards = torch.randint(0, 12, (B, 16), dtype=torch.uint8, device=dev)
-for _ in range(3): fp.features(boards)
-torch.cuda.synchronize(); t = time.time()
-for _ in range(10): fp.features(boards)
-torch.cuda.synchronize(); print(f"B={B}: {(time.time()-t)/10*1e3:.3f} ms per forward; tiles per CU {B/7/256:.2f}")
+for split in (False, True):
+    for _ in range(3): fp.features(boards, split=split)
+    torch.cuda.synchronize(); t = time.time()
+    for _ in range(10): fp.features(boards, split=split)
+    torch.cuda.synchronize(); print(f"B={B} split={split}: {(time.time()-t)/10*1e3:.3f} ms per forward; tiles per CU {B/7/256:.2f}")
+a, b = fp.features(boards, split=False), fp.features(boards, split=True)
+print("split vs single kernel: max |diff|", (a - b).abs().max().item(), "mean |diff|", (a - b).abs().mean().item(), "scale", a.abs().mean().item())
