@@ -113,7 +113,10 @@ __global__ void __launch_bounds__(64) k_attn_fwd17(Params P, uint16_t *__restric
     }
     __syncthreads();
     if (!active) return;
+    // The loops over the 17 keys stay ROLLED (s[] lives in registers through indexed moves): fully unrolled, the
+    // compiler hoists the LDS reads of every row, needs all 512 registers plus scratch and runs one wave per SIMD.
     float s[SK], m = -3.0e38f;
+#pragma unroll 1
     for (int j = 0; j < SK; ++j) {
         s[j] = dot_lds(q, Ks + pl * PSTRIDE + j * ROW) * P.scale;
         m = fmaxf(m, s[j]);
@@ -127,6 +130,7 @@ __global__ void __launch_bounds__(64) k_attn_fwd17(Params P, uint16_t *__restric
     const uint64_t base = ((uint64_t)pair * SK + i) * 32;
     float acc[HD];
     for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+#pragma unroll 1
     for (int j = 0; j < SK; ++j) {
         const float pj = (P.p_drop > 0.f && !keep_mask(P, base + j)) ? 0.f : s[j] * inv * P.inv_keep;
         axpy_lds(acc, pj, Vs + pl * PSTRIDE + j * ROW);
@@ -139,8 +143,11 @@ __global__ void __launch_bounds__(64) k_attn_bwd17(Params P, const uint16_t *__r
                                                    uint16_t *__restrict__ dq, uint16_t *__restrict__ dk,
                                                    uint16_t *__restrict__ dv) {
     mix_seed_state(P);
-    __shared__ float Ks[PAIRS * PSTRIDE], Vs[PAIRS * PSTRIDE], Qs[PAIRS * PSTRIDE], Gs[PAIRS * PSTRIDE];
+    // K/V tiles serve the first phase (dS, dQ), then the same LDS holds Q/dO for the second (dK, dV): 22 KB per
+    // workgroup instead of 37, i.e. 7 resident waves per CU instead of 4
+    __shared__ float Ks[PAIRS * PSTRIDE], Vs[PAIRS * PSTRIDE];
     __shared__ float dSs[PAIRS * SK * (SK + 1)], Pt[PAIRS * SK * (SK + 1)];
+    float *const Qs = Ks, *const Gs = Vs;
     const int lane = threadIdx.x, pl = lane / SK, i = lane - pl * SK;
     const int64_t pair = (int64_t)blockIdx.x * PAIRS + pl;
     const bool active = pl < PAIRS && pair < P.B * P.H;
@@ -153,15 +160,14 @@ __global__ void __launch_bounds__(64) k_attn_bwd17(Params P, const uint16_t *__r
         load_row(P.v + b * P.v_sb + i * P.v_ss + h * HD, t);
         put_row(Vs + pl * PSTRIDE + i * ROW, t);
         load_row(P.q + b * P.q_sb + i * P.q_ss + h * HD, q);
-        put_row(Qs + pl * PSTRIDE + i * ROW, q);
         load_row(dout + ((b * SK + i) * P.H + h) * HD, g);
-        put_row(Gs + pl * PSTRIDE + i * ROW, g);
     }
     __syncthreads();
     if (active) {
         const float L = lse[(b * P.H + h) * SK + i];
         const uint64_t base = ((uint64_t)pair * SK + i) * 32;
         float p[SK], dp[SK], delta = 0.f;
+#pragma unroll 1
         for (int j = 0; j < SK; ++j) {
             p[j] = __expf(dot_lds(q, Ks + pl * PSTRIDE + j * ROW) * P.scale - L);
             const bool keep = !(P.p_drop > 0.f) || keep_mask(P, base + j);
@@ -171,6 +177,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd17(Params P, const uint16_t *__r
         }
         float acc[HD];
         for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+#pragma unroll 1
         for (int j = 0; j < SK; ++j) {
             const float ds = p[j] * (dp[j] - delta) * P.scale;
             dSs[(pl * SK + i) * (SK + 1) + j] = ds;
@@ -178,11 +185,17 @@ __global__ void __launch_bounds__(64) k_attn_bwd17(Params P, const uint16_t *__r
         }
         store_row(dq + b * P.q_sb + i * P.q_ss + h * HD, acc);
     }
+    __syncthreads();  // every lane is done with K/V
+    if (active) {
+        put_row(Qs + pl * PSTRIDE + i * ROW, q);
+        put_row(Gs + pl * PSTRIDE + i * ROW, g);
+    }
     __syncthreads();
     if (!active) return;
     // this lane now owns key/value row j = i of its pair
     float ak[HD], av[HD];
     for (int d = 0; d < HD; ++d) ak[d] = av[d] = 0.f;
+#pragma unroll 1
     for (int r = 0; r < SK; ++r) {
         axpy_lds(ak, dSs[(pl * SK + r) * (SK + 1) + i], Qs + pl * PSTRIDE + r * ROW);
         axpy_lds(av, Pt[(pl * SK + r) * (SK + 1) + i], Gs + pl * PSTRIDE + r * ROW);
