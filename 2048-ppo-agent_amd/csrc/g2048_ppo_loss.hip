@@ -104,3 +104,43 @@ extern "C" int g2048_ppo_loss(const void *logits, int logits_bf16, const void *v
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }
+
+// ---- minibatch gather ------------------------------------------------------------------------------------------------
+// One launch instead of six index_select kernels (+ six copies into the hipGraph's static inputs): sample idx[i] of the
+// rollout buffer -> row i of the minibatch.  Reference: the DataLoader collation over PPODataset.__getitem__
+// (src/ppo/data_loader.py) - here the buffer never leaves the device.
+namespace {
+
+__global__ void __launch_bounds__(256)
+k_gather_minibatch(const int64_t *__restrict__ idx, int64_t M, int64_t N, const uint4 *__restrict__ boards,
+                   const uint8_t *__restrict__ actions, const uint8_t *__restrict__ masks, const float *__restrict__ logp,
+                   const float *__restrict__ adv, const float *__restrict__ ret, uint4 *__restrict__ o_boards,
+                   uint8_t *__restrict__ o_actions, uint8_t *__restrict__ o_masks, float *__restrict__ o_logp,
+                   float *__restrict__ o_adv, float *__restrict__ o_ret) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    int64_t s = idx[i];
+    s = s < 0 ? 0 : (s >= N ? N - 1 : s);  // never read out of bounds on a bad index
+    o_boards[i] = boards[s];
+    o_actions[i] = actions[s];
+    o_masks[i] = masks[s];
+    o_logp[i] = logp[s];
+    o_adv[i] = adv[s];
+    o_ret[i] = ret[s];
+}
+
+}  // namespace
+
+extern "C" int g2048_gather_minibatch(const int64_t *idx, int64_t M, int64_t N, const uint8_t *boards, const uint8_t *actions,
+                                      const uint8_t *masks, const float *logp, const float *adv, const float *ret,
+                                      uint8_t *o_boards, uint8_t *o_actions, uint8_t *o_masks, float *o_logp, float *o_adv,
+                                      float *o_ret, void *stream) {
+    if (!idx || !boards || !actions || !masks || !logp || !adv || !ret || !o_boards || !o_actions || !o_masks || !o_logp ||
+        !o_adv || !o_ret || M <= 0 || N <= 0 || (((uintptr_t)boards | (uintptr_t)o_boards) & 15))
+        return G2048_EINVAL;
+    hipLaunchKernelGGL(k_gather_minibatch, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, M, N,
+                       (const uint4 *)boards, actions, masks, logp, adv, ret, (uint4 *)o_boards, o_actions, o_masks, o_logp, o_adv,
+                       o_ret);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(1000 + (int)e);
+}

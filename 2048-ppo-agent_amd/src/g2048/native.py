@@ -54,6 +54,7 @@ SIGNATURES = {
     "g2048_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_embed_bwd_workspace_floats": [_i64],
     "g2048_embed_bwd": [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_gather_minibatch": [_vp, _i64, _i64] + [_vp] * 13,
     "g2048_colsum_workspace_floats": [_i64, _i32],
     "g2048_colsum": [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp],
     "g2048_add_ln_bwd_workspace_floats": [_i64],
@@ -405,3 +406,21 @@ def embed_bwd(boards, dx0, dwt_dcls, p_drop: float = 0.0, seed: int = 0, seed_st
     _check(load().g2048_embed_bwd(_dev(boards, u8, 16 * M, "boards"), _dev(dx0, f32, M * 17 * 256, "dx0"),
                                   _dev(dwt_dcls, f32, 32 * 256, "dwt_dcls"), ws.data_ptr(), M, float(p_drop), int(seed),
                                   seed_state or None, _stream()), "g2048_embed_bwd")
+
+
+def gather_minibatch(idx, boards, actions, masks, logp, adv, ret, out=None):
+    """-> dict(obs u8 [M,16], actions u8 [M], masks u8 [M], old_lp, adv, ret f32 [M]) = rows idx of the buffer (``out``:
+    pre-allocated tensors of that layout, e.g. the static inputs of a captured graph)."""
+    M, N = idx.numel(), actions.numel()
+    dev = boards.device
+    if out is None:
+        out = dict(obs=torch.empty((M, 16), dtype=u8, device=dev), actions=torch.empty(M, dtype=u8, device=dev),
+                   masks=torch.empty(M, dtype=u8, device=dev), old_lp=torch.empty(M, dtype=f32, device=dev),
+                   adv=torch.empty(M, dtype=f32, device=dev), ret=torch.empty(M, dtype=f32, device=dev))
+    _check(load().g2048_gather_minibatch(
+        _dev(idx, i64, M, "idx"), M, N, _dev(boards, u8, 16 * N, "boards"), _dev(actions, u8, N, "actions"),
+        _dev(masks, u8, N, "masks"), _dev(logp, f32, N, "logp"), _dev(adv, f32, N, "adv"), _dev(ret, f32, N, "ret"),
+        _dev(out["obs"], u8, 16 * M, "o_boards"), _dev(out["actions"], u8, M, "o_actions"), _dev(out["masks"], u8, M, "o_masks"),
+        _dev(out["old_lp"], f32, M, "o_logp"), _dev(out["adv"], f32, M, "o_adv"), _dev(out["ret"], f32, M, "o_ret"), _stream()),
+        "g2048_gather_minibatch")
+    return out

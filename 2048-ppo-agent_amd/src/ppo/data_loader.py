@@ -127,7 +127,8 @@ class DeviceBatches:
         n = len(self.ds)
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
-    def epoch(self):
+    def indices(self):
+        """One epoch of minibatch index tensors (int64 on the data's device)."""
         ds = self.ds
         ds.reset_epoch()
         n = len(ds)
@@ -136,9 +137,30 @@ class DeviceBatches:
             order = ds.active_indices[order]
         stop = n - (n % self.batch_size) if self.drop_last else n
         for s in range(0, stop, self.batch_size):
-            idx = order[s:s + self.batch_size]
-            yield {
-                "observations": ds.observations.index_select(0, idx), "actions": ds.actions.index_select(0, idx),
-                "action_masks": ds.action_masks.index_select(0, idx), "log_probs": ds.log_probs.index_select(0, idx),
-                "advantages": ds.advantages.index_select(0, idx), "returns": ds.returns.index_select(0, idx),
-            }
+            yield order[s:s + self.batch_size]
+
+    def packed(self) -> bool:
+        """Device-resident packed layout (boards u8 [N, 16], actions / mask bits u8 [N]): ``gather_packed`` applies."""
+        ds = self.ds
+        return (ds.observations.is_cuda and ds.observations.dtype == torch.uint8 and ds.observations.dim() == 2
+                and ds.observations.shape[1] == 16 and ds.actions.dtype == torch.uint8 and ds.actions.dim() == 1
+                and ds.action_masks.dtype == torch.uint8 and ds.action_masks.dim() == 1)
+
+    def gather_packed(self, idx: torch.Tensor, out=None) -> dict:
+        """-> dict(obs, actions, masks, old_lp, adv, ret) for the samples ``idx`` in ONE launch (``g2048_gather_minibatch``),
+        optionally straight into pre-allocated tensors (the static inputs of the captured update)."""
+        ds = self.ds
+        return nv.gather_minibatch(idx.contiguous(), ds.observations, ds.actions, ds.action_masks, ds.log_probs, ds.advantages,
+                                   ds.returns, out)
+
+    def gather(self, idx: torch.Tensor) -> dict:
+        ds = self.ds
+        return {
+            "observations": ds.observations.index_select(0, idx), "actions": ds.actions.index_select(0, idx),
+            "action_masks": ds.action_masks.index_select(0, idx), "log_probs": ds.log_probs.index_select(0, idx),
+            "advantages": ds.advantages.index_select(0, idx), "returns": ds.returns.index_select(0, idx),
+        }
+
+    def epoch(self):
+        for idx in self.indices():
+            yield self.gather(idx)

@@ -142,6 +142,10 @@ class _GraphedFwdBwd:
     def run(self, batch: dict):
         for k, v in batch.items():
             self.static[k].copy_(v)
+        return self.replay()
+
+    def replay(self):
+        """Replay on whatever ``self.static`` holds (the minibatch gather kernel writes there directly)."""
         self.graph.replay()
         for p, g in zip(self.tr.agent.parameters(), self.grads):  # an eager step in between may have re-pointed them
             p.grad = g
@@ -332,6 +336,18 @@ class PPOTrainer:
         loss = (policy_loss + self.value_loss_coef * value_loss + self.entropy_coef * entropy_loss).mean()
         return loss, policy_loss, value_loss, entropy_loss, new_log_probs
 
+    def _build_graph(self, gkey, batch_size: int, sample: dict):
+        """Capture the update for this minibatch layout; on failure fall back to eager mode for good (None)."""
+        try:
+            self._graphs[gkey] = _GraphedFwdBwd(self, batch_size, sample)
+        except Exception as e:  # the eager path computes the same thing, only slower: never lose a run
+            logger.warning("hipGraph capture of the update failed (%s); continuing in eager mode", e)
+            self.use_hip_graph = False
+            self._graphs.clear()
+            self.optimizer.zero_grad(set_to_none=True)
+            return None
+        return self._graphs[gkey]
+
     def _fused_loss_ok(self) -> bool:
         return self.device.type == "cuda" and getattr(self.agent, "action_dim", 4) == 4
 
@@ -417,30 +433,35 @@ class PPOTrainer:
         sums = torch.zeros(4, dtype=torch.float64, device=self.device)  # policy, value, entropy, total
         n_updates = 0
         mean_kl = 0.0
+        packed = self._fused_loss_ok() and batches.packed()
         for epoch in range(n_epochs):
             kl_sum = torch.zeros(1, dtype=torch.float64, device=self.device)
             done_batches = 0
-            for batch in batches.epoch():
+            for idx in batches.indices():
                 if done_batches >= n_per_epoch:
                     break
-                obs, actions, masks, old_lp, adv, ret = self._unpack_batch(batch, packed=self._fused_loss_ok())
-                graphed = None
-                if self.use_hip_graph and obs.shape[0] == batch_size:
-                    sample = dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret)
-                    gkey = (batch_size, obs.dtype, tuple(obs.shape[1:]))
-                    if gkey not in self._graphs:
-                        try:
-                            self._graphs[gkey] = _GraphedFwdBwd(self, batch_size, sample)
-                        except Exception as e:  # the eager path computes the same thing, only slower: never lose a run
-                            logger.warning("hipGraph capture of the update failed (%s); continuing in eager mode", e)
-                            self.use_hip_graph = False
-                            self._graphs.clear()
-                            self.optimizer.zero_grad(set_to_none=True)
-                    graphed = self._graphs.get(gkey)
-                if graphed is not None:
-                    stats, kl = graphed.run(sample)
+                full = idx.numel() == batch_size
+                if packed:
+                    # device-resident packed buffer: one gather launch, straight into the graph's static inputs
+                    gkey = (batch_size, "packed")
+                    graphed = self._graphs.get(gkey) if (self.use_hip_graph and full) else None
+                    if graphed is not None:
+                        batches.gather_packed(idx, out=graphed.static)
+                        stats, kl = graphed.replay()
+                    else:
+                        sample = batches.gather_packed(idx)
+                        if self.use_hip_graph and full:
+                            graphed = self._build_graph(gkey, batch_size, sample)
+                        stats, kl = graphed.run(sample) if graphed is not None else self._loss_backward(**sample)
                 else:
-                    stats, kl = self._loss_backward(obs, actions, masks, old_lp, adv, ret)
+                    obs, actions, masks, old_lp, adv, ret = self._unpack_batch(batches.gather(idx),
+                                                                               packed=self._fused_loss_ok())
+                    sample = dict(obs=obs, actions=actions, masks=masks, old_lp=old_lp, adv=adv, ret=ret)
+                    graphed = None
+                    if self.use_hip_graph and full:
+                        gkey = (batch_size, obs.dtype, tuple(obs.shape[1:]))
+                        graphed = self._graphs.get(gkey) or self._build_graph(gkey, batch_size, sample)
+                    stats, kl = graphed.run(sample) if graphed is not None else self._loss_backward(**sample)
                 self._allreduce_grads()
                 if self.use_amp:
                     self.scaler.unscale_(self.optimizer)

@@ -257,6 +257,15 @@ int64_t g2048_embed_bwd_workspace_floats(int64_t M);
 int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, float *workspace, int64_t M, float p_drop,
                     uint64_t seed, const uint64_t *seed_state, void *stream);
 
+/* ---- PPO update: minibatch assembly ------------------------------------------------------------------------ */
+
+/* Row i of the minibatch = sample idx[i] (int64, clamped to [0, N)) of the device-resident rollout buffer: boards
+ * u8 [N][16], actions u8 [N], masks u8 [N], logp / adv / ret f32 [N] -> the o_* arrays of M rows.  One launch for what
+ * the reference's DataLoader collation does per field (PPODataset.__getitem__, src/ppo/data_loader.py). */
+int g2048_gather_minibatch(const int64_t *idx, int64_t M, int64_t N, const uint8_t *boards, const uint8_t *actions,
+                           const uint8_t *masks, const float *logp, const float *adv, const float *ret, uint8_t *o_boards,
+                           uint8_t *o_actions, uint8_t *o_masks, float *o_logp, float *o_adv, float *o_ret, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

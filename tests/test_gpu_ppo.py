@@ -608,3 +608,22 @@ def test_embed_boards_matches_torch(dev):
         counts[e] = (kept & (boards == e).unsqueeze(-1)).sum() / 256.0
     assert torch.allclose(w.grad.mean(0), counts / 0.9, rtol=1e-2, atol=1e-2)  # masked the same way as the forward
     assert torch.allclose(cls.grad.reshape(-1), torch.full((256,), 4096.0, device=dev))
+
+
+def test_gather_minibatch_matches_index_select(dev):
+    """g2048_gather_minibatch == six index_selects; also straight into pre-allocated (static) outputs."""
+    from src.g2048 import native as nv
+
+    torch.manual_seed(19)
+    N = 100003
+    boards = torch.randint(0, 16, (N, 16), device=dev, dtype=torch.uint8)
+    actions = torch.randint(0, 4, (N,), device=dev, dtype=torch.uint8)
+    masks = torch.randint(1, 16, (N,), device=dev, dtype=torch.uint8)
+    logp, adv, ret = (torch.randn(N, device=dev) for _ in range(3))
+    for M in (1, 255, 2048, 5001):
+        idx = torch.randint(0, N, (M,), device=dev)
+        got = nv.gather_minibatch(idx, boards, actions, masks, logp, adv, ret)
+        for k, src in (("obs", boards), ("actions", actions), ("masks", masks), ("old_lp", logp), ("adv", adv), ("ret", ret)):
+            assert torch.equal(got[k], src.index_select(0, idx)), k
+        again = nv.gather_minibatch(idx.flip(0), boards, actions, masks, logp, adv, ret, out=got)
+        assert again is got and torch.equal(got["obs"], boards.index_select(0, idx.flip(0)))
