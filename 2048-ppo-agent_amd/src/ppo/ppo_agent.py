@@ -12,7 +12,8 @@ import torch.nn.functional as F
 from torch.distributions import Categorical
 
 from ..env_definitions import ACTION_DIM, OBS_DIM
-from .transformer_encoder import Bf16Shadow, TransformerEncoder, _linear, _train_bf16
+from .hip_ops import Bf16Shadow, _linear, _train_bf16
+from .transformer_encoder import TransformerEncoder
 
 
 def _one_hot(boards: torch.Tensor, classes: int, dtype) -> torch.Tensor:

@@ -26,7 +26,7 @@ from ..runs.batch_runner import BatchRunner
 from .data_loader import DeviceBatches, PPODataset
 from .rollout_buffer import RolloutBuffer
 from .torch_action_wrapper import TorchActionFunction
-from .transformer_encoder import Bf16Shadow, graph_seed_state
+from .hip_ops import Bf16Shadow, graph_seed_state
 
 logger = logging.getLogger(__name__)
 

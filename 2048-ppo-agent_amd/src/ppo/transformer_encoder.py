@@ -2,11 +2,11 @@
 
 Parameter/buffer names are the reference's (``positional_encoding.{inv_freq,pe}``, ``cls_token``,
 ``encoder.layers.N.*`` of ``nn.TransformerEncoder``) so checkpoints interchange; the forward is written
-out explicitly (pre-norm layers over fused QKV + SDPA) so the rollout and update paths control dtype and
-can be captured in hipGraphs.  The GEMMs run on MFMA through hipBLASLt.
+out explicitly (pre-norm layers over fused QKV) so that the update path can run through the HIP kernels bound in
+``hip_ops.py`` (attention, add + dropout + LayerNorm, Linear blocks, token embedding) and be captured in a hipGraph;
+without a HIP device, gradients or bf16 autocast every step falls back to the PyTorch operator it mirrors.
 """
 import math
-import weakref
 
 import torch
 import torch.nn as nn
@@ -14,472 +14,9 @@ import torch.nn.functional as F
 
 from ..env_definitions import BOARD_DIM
 
-
-class Bf16Shadow:
-    """bf16 copies of a list of f32 master parameters inside one flat buffer, refreshed by ONE multi-tensor copy
-    whenever a master changed (in-place updates bump ``Tensor._version``; a re-allocated master changes the data
-    pointer).  Under autocast every minibatch otherwise re-casts each weight and bias with its own 4-microsecond kernel
-    (about 50 launches per PPO minibatch, and the update is launch-bound)."""
-
-    _live = weakref.WeakSet()
-
-    def __init__(self, params, transposed=()):
-        self.params = list(params)
-        self.key, self.flat, self.views = None, None, None
-        self.transposed = tuple(transposed)  # indices of 2-D params that also get a [in, out] copy (``tviews[i]``)
-        self.tviews = {}
-        Bf16Shadow._live.add(self)
-
-    def invalidate(self):
-        self.key = None
-
-    @staticmethod
-    def invalidate_all():
-        """Force the next use of every shadow to re-copy (called before a hipGraph capture so that the copy becomes
-        part of the graph: a replay runs no Python and would otherwise read stale shadows)."""
-        for s in list(Bf16Shadow._live):
-            s.invalidate()
-
-    def __call__(self):
-        ps = self.params
-        key = (ps[0].data_ptr(), sum(p._version for p in ps))
-        if key != self.key:
-            if self.flat is None or self.flat.device != ps[0].device:
-                offs, n = [], 0
-                for q in ps:
-                    offs.append(n)
-                    n += (q.numel() + 63) // 64 * 64  # keep every view 128-byte aligned for the GEMMs
-                self.flat = torch.empty(n, dtype=torch.bfloat16, device=ps[0].device)
-                self.views = [self.flat[o:o + q.numel()].view(q.shape) for o, q in zip(offs, ps)]
-                self.tviews = {i: torch.empty(ps[i].shape[::-1], dtype=torch.bfloat16, device=ps[0].device)
-                               for i in self.transposed}
-            with torch.no_grad():
-                torch._foreach_copy_(self.views, [q.detach() for q in ps])
-                for i, tv in self.tviews.items():
-                    tv.copy_(self.views[i].t())
-            self.key = key
-        return self.views
-
-
-def _sum_f32(t: torch.Tensor, dim: int = 0) -> torch.Tensor:
-    return torch.sum(t, dim, dtype=torch.float32)
-
-
-def _colsum(t: torch.Tensor, out=None) -> torch.Tensor:
-    """f32 column sums of a [rows, N] device tensor (bias gradients): ``g2048_colsum`` (fixed summation order and safe
-    inside a replayed hipGraph, unlike at::sum's semaphore-based cross-workgroup stage) when the shape allows."""
-    N = t.shape[-1]
-    if t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and N % 4 == 0 and N <= 1024 and t.stride(0) % 4 == 0 \
-            and t.dtype in (torch.bfloat16, torch.float32):
-        from ..g2048 import native as nv
-
-        return nv.colsum(t, out)
-    if out is None:
-        return _sum_f32(t)
-    return torch.sum(t, 0, dtype=torch.float32, out=out)
-
-
-class _ExpandRows(torch.autograd.Function):
-    """``t.expand(B, -1, -1)`` of a [1, 1, D] parameter whose gradient (a sum over B rows) goes through ``_colsum``."""
-
-    @staticmethod
-    def forward(ctx, t, B):
-        return t.expand(B, -1, -1)
-
-    @staticmethod
-    def backward(ctx, g):
-        return _colsum(g.reshape(g.shape[0], -1)).view(1, 1, -1), None
-
-
-def _hip_linear(x2: torch.Tensor, wb: torch.Tensor, bias_f32=None):
-    """x2 @ wb^T (+ bias) through ``g2048_linear_bf16`` for the shapes where its weights-stationary layout beats
-    hipBLASLt's pick on this chip (K <= 256 with a wide output: linear1 forward 55 -> 38 us, linear2 input gradient
-    48 -> 38 us at 34 816 tokens; tools/probe_linear.py), else None."""
-    K, N = x2.shape[-1], wb.shape[0]
-    if K > 256 or N < 512 or N % 256 or x2.shape[0] < 4096:
-        return None
-    from ..g2048 import native as nv
-
-    if not nv.linear_ok(x2, wb):
-        return None
-    return nv.linear_bf16(x2, wb, bias_f32)
-
-
-def _dweight(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
-    """dW = dY^T X in f32 from bf16 operands.  It reduces over every token of the minibatch (34 816 at minibatch 2048)
-    into a tiny [out, in] matrix; hipBLASLt runs that as 16-64 workgroups on 256 CUs (177 us per GEMM).  Cutting the
-    token axis into 16 slices turns it into a batched GEMM with 16x the workgroups plus an f32 sum of the partials:
-    42 us, 4x faster, and the f32 sum is at least as accurate as the single bf16-output GEMM it replaces
-    (tools/probe_splitk.py)."""
-    T, S = x2.shape[0], _LinearSplitK.SLICES
-    if T % S == 0 and T // S >= 1024:
-        return _sum_f32(torch.bmm(dy2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1)))
-    return (dy2.t() @ x2).float()
-
-
-class _LinearSplitK(torch.autograd.Function):
-    """``F.linear`` in bf16 (what autocast does) with a split-K weight gradient (``_dweight``), f32 gradients for the f32
-    master weight/bias produced directly by the reductions, and optional pre-cast bf16 shadows ``wb``/``bb`` of the
-    masters (``Bf16Shadow``) so that no cast kernels run per call."""
-
-    SLICES = 16
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, wb=None, bb=None):
-        with torch.autocast("cuda", enabled=False):
-            xb = x.to(torch.bfloat16)
-            if wb is None:
-                wb = weight.to(torch.bfloat16)
-            if bias is not None and bb is None:
-                bb = bias.to(torch.bfloat16)
-            y = F.linear(xb, wb, bb)
-        ctx.save_for_backward(xb, wb)
-        ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        xb, wb = ctx.saved_tensors
-        x_dtype, w_dtype, b_dtype = ctx.meta
-        with torch.autocast("cuda", enabled=False):
-            dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16)
-            x2 = xb.reshape(-1, xb.shape[-1])
-            dx = (dy2 @ wb).view(xb.shape).to(x_dtype) if ctx.needs_input_grad[0] else None
-            dw = _dweight(dy2, x2).to(w_dtype)
-            db = None if b_dtype is None else _colsum(dy2).to(b_dtype)
-        return dx, dw, db, None, None
-
-
-class _InProjCls(torch.autograd.Function):
-    """in_proj of the LAST layer when only the CLS row is wanted: q = h[:, :1] Wq^T + bq, kv = h Wkv^T + bkv, with
-    the gradients of the whole in_proj weight and bias assembled in one buffer (slicing the parameter instead costs a
-    zero-fill, a copy and an accumulate per slice in the backward).  h, wb, bb bf16; weight/bias the f32 masters."""
-
-    @staticmethod
-    def forward(ctx, h, weight, bias, wb, bb):
-        D = h.shape[-1]
-        q = F.linear(h[:, :1], wb[:D], bb[:D])
-        kv = F.linear(h, wb[D:], bb[D:])
-        ctx.save_for_backward(h, wb)
-        return q, kv
-
-    @staticmethod
-    def backward(ctx, dq, dkv):
-        h, wb = ctx.saved_tensors
-        B, S, D = h.shape
-        dq2, dkv2 = dq.reshape(B, D).contiguous(), dkv.reshape(B * S, 2 * D)
-        dh = (dkv2 @ wb[D:]).view(B, S, D)
-        dh[:, 0] += dq2 @ wb[:D]
-        dw = torch.empty((3 * D, D), dtype=torch.float32, device=h.device)
-        dw[:D] = dq2.t() @ h[:, 0]
-        dw[D:] = _dweight(dkv2, h.view(B * S, D))
-        db = torch.empty(3 * D, dtype=torch.float32, device=h.device)
-        _colsum(dq2, db[:D])
-        _colsum(dkv2, db[D:])
-        return dh, dw, db, None, None
-
-
-def _seed() -> int:
-    return int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
-
-
-_GRAPH_SEED = {}  # device -> int64[1] word the dropout kernels of a captured region mix into their seed
-_capture_site = [0]
-
-
-def graph_seed_state(device) -> torch.Tensor:
-    """The device-resident seed word for hipGraph-captured dropout: whoever replays a captured update advances it
-    (``.add_(1)``, inside or outside the graph) so that every replay draws new masks."""
-    device = torch.device(device)
-    if device not in _GRAPH_SEED:
-        _GRAPH_SEED[device] = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
-    return _GRAPH_SEED[device]
-
-
-def _seed_pair(t: torch.Tensor, p_drop: float):
-    """(seed, seed_state address) for a dropout kernel launch: a fresh host-side seed in eager mode; while a hipGraph is
-    being captured the launch arguments are frozen, so the seed is a per-call-site constant and the randomness comes
-    from ``graph_seed_state`` read by the kernel at run time."""
-    if p_drop <= 0:
-        return 0, 0
-    if torch.cuda.is_current_stream_capturing():
-        _capture_site[0] += 1
-        return (_capture_site[0] * 0x9E3779B97F4A7C15) & (2 ** 62 - 1), graph_seed_state(t.device).data_ptr()
-    return _seed(), 0
-
-
-class _AttnPacked(torch.autograd.Function):
-    """Self-attention over the packed in_proj output ``qkv`` [B, 17, 3*H*32] (bf16) through the HIP kernels
-    ``g2048_attn_fwd/bwd``; returns [B, 17, H*32] already in the layout out_proj reads.  The gradient is written
-    straight into a packed d(qkv) buffer.  Dropout acts on the attention probabilities, as nn.MultiheadAttention's."""
-
-    @staticmethod
-    def forward(ctx, qkv, nhead, p_drop):
-        from ..g2048 import native as nv
-
-        B, S, W = qkv.shape
-        hw = W // 3
-        qkv = qkv.contiguous()
-        o = torch.empty((B, S, hw), dtype=torch.bfloat16, device=qkv.device)
-        lse = torch.empty((B, nhead, S), dtype=torch.float32, device=qkv.device)
-        seed = _seed_pair(qkv, p_drop)
-        base = qkv.data_ptr()
-        strides = (S * W, W) * 3
-        nv.attn_fwd(base, base + 2 * hw, base + 4 * hw, o, lse, B, nhead, S, strides, (hw // nhead) ** -0.5, p_drop, *seed)
-        ctx.save_for_backward(qkv, lse)
-        ctx.meta = (nhead, p_drop, seed)
-        return o
-
-    @staticmethod
-    def backward(ctx, do):
-        from ..g2048 import native as nv
-
-        qkv, lse = ctx.saved_tensors
-        nhead, p_drop, seed = ctx.meta
-        B, S, W = qkv.shape
-        hw = W // 3
-        dqkv = torch.empty_like(qkv)
-        base, dbase = qkv.data_ptr(), dqkv.data_ptr()
-        nv.attn_bwd(base, base + 2 * hw, base + 4 * hw, do.contiguous(), lse, dbase, dbase + 2 * hw, dbase + 4 * hw, B,
-                    nhead, S, (S * W, W) * 3, (hw // nhead) ** -0.5, p_drop, *seed)
-        return dqkv, None, None
-
-
-class _AttnCls(torch.autograd.Function):
-    """The CLS query of the last layer against all 17 keys: q [B, 1, H*32], kv [B, 17, 2*H*32] (bf16)."""
-
-    @staticmethod
-    def forward(ctx, q, kv, nhead, p_drop):
-        from ..g2048 import native as nv
-
-        B, S, W = kv.shape
-        hw = W // 2
-        q, kv = q.contiguous(), kv.contiguous()
-        o = torch.empty((B, 1, hw), dtype=torch.bfloat16, device=kv.device)
-        lse = torch.empty((B, nhead, 1), dtype=torch.float32, device=kv.device)
-        seed = _seed_pair(kv, p_drop)
-        kb = kv.data_ptr()
-        nv.attn_fwd(q.data_ptr(), kb, kb + 2 * hw, o, lse, B, nhead, 1, (hw, 0, S * W, W, S * W, W),
-                    (hw // nhead) ** -0.5, p_drop, *seed)
-        ctx.save_for_backward(q, kv, lse)
-        ctx.meta = (nhead, p_drop, seed)
-        return o
-
-    @staticmethod
-    def backward(ctx, do):
-        from ..g2048 import native as nv
-
-        q, kv, lse = ctx.saved_tensors
-        nhead, p_drop, seed = ctx.meta
-        B, S, W = kv.shape
-        hw = W // 2
-        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-        kb, db = kv.data_ptr(), dkv.data_ptr()
-        nv.attn_bwd(q.data_ptr(), kb, kb + 2 * hw, do.contiguous(), lse, dq.data_ptr(), db, db + 2 * hw, B, nhead, 1,
-                    (hw, 0, S * W, W, S * W, W), (hw // nhead) ** -0.5, p_drop, *seed)
-        return dq, dkv, None, None
-
-
-class _AddLayerNorm(torch.autograd.Function):
-    """``x_new = x + dropout(a); h = LayerNorm(x_new).bfloat16()`` in one HIP kernel each way (``g2048_add_ln_fwd/bwd``):
-    the tail of one pre-norm sub-layer fused with the head of the next.  ``a`` None: ``h = LayerNorm(x)`` only.
-    x f32 [..., 256] (a [B, 1, 256] slice of the residual stream is read in place), a bf16; returns (x_new, h)."""
-
-    @staticmethod
-    def forward(ctx, x, a, gamma, beta, eps, p_drop):
-        from ..g2048 import native as nv
-
-        x, row_stride = _residual_rows(x)
-        T = x.numel() // 256
-        gamma, beta = gamma.contiguous(), beta.contiguous()
-        h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-        stats = torch.empty((2, T), dtype=torch.float32, device=x.device)
-        x_new = None
-        seed = (0, 0)
-        if a is not None:
-            a = a.contiguous()
-            x_new = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-            seed = _seed_pair(x, p_drop)
-        nv.add_ln_fwd(x.data_ptr(), row_stride, a, gamma, beta, x_new, h, stats[0], stats[1], T, eps, p_drop, *seed)
-        if a is None:
-            ctx.save_for_backward(x, gamma, stats)
-            ctx.meta = (row_stride, 0.0, (0, 0), False)
-            unused = x.new_empty(0)
-            ctx.mark_non_differentiable(unused)
-            return unused, h
-        ctx.save_for_backward(x_new, gamma, stats)
-        ctx.meta = (256, p_drop, seed, True)
-        return x_new, h
-
-    @staticmethod
-    def backward(ctx, g_x, g_h):
-        from ..g2048 import native as nv
-
-        xn, gamma, stats = ctx.saved_tensors
-        row_stride, p_drop, seed, has_a = ctx.meta
-        T = xn.numel() // 256
-        dx = torch.empty(xn.shape, dtype=torch.float32, device=xn.device)
-        da = torch.empty(xn.shape, dtype=torch.bfloat16, device=xn.device) if has_a else None
-        dparams = torch.empty((3, 256), dtype=torch.float32, device=xn.device)
-        if g_h is None:
-            g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
-        g_x = g_x.contiguous() if (has_a and g_x is not None) else None
-        nv.add_ln_bwd(xn.data_ptr(), row_stride, g_x, g_h.contiguous(), stats[0], stats[1], gamma, dx, da, dparams, T, p_drop,
-                      *seed)
-        return dx, da, dparams[0], dparams[1], None, None
-
-
-def _residual_rows(x: torch.Tensor):
-    """(x, row stride): a [B, 1, 256] slice of the residual stream is read in place by the add+LayerNorm kernels."""
-    if x.dim() == 3 and x.shape[1] == 1 and x.stride(2) == 1 and x.stride(0) % 4 == 0:
-        return x, x.stride(0)
-    return x.contiguous(), x.shape[-1]
-
-
-class _LinearAddLayerNorm(torch.autograd.Function):
-    """``a = Linear(u); x_new = x + dropout(a); h = LayerNorm(x_new).bfloat16()``: the closing Linear of a sub-layer
-    (out_proj / linear2) fused with ``_AddLayerNorm``.  The Linear's bias gradient (column sums of da) comes out of
-    ``g2048_add_ln_bwd`` for free, its weight gradient is the split-K product.  u bf16, wb/bb bf16 shadows of the f32
-    masters weight/bias, x f32; returns (x_new, h)."""
-
-    @staticmethod
-    def forward(ctx, u, weight, bias, wb, bb, x, gamma, beta, eps, p_drop, wbT=None):
-        from ..g2048 import native as nv
-
-        with torch.autocast("cuda", enabled=False):
-            a = F.linear(u, wb, bb)
-        ctx.wbT = wbT
-        x, row_stride = _residual_rows(x)
-        T = x.numel() // 256
-        gamma, beta = gamma.contiguous(), beta.contiguous()
-        h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-        x_new = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-        stats = torch.empty((2, T), dtype=torch.float32, device=x.device)
-        seed = _seed_pair(x, p_drop)
-        nv.add_ln_fwd(x.data_ptr(), row_stride, a, gamma, beta, x_new, h, stats[0], stats[1], T, eps, p_drop, *seed)
-        ctx.save_for_backward(u, wb, x_new, gamma, stats)
-        ctx.meta = (p_drop, seed)
-        return x_new, h
-
-    @staticmethod
-    def backward(ctx, g_x, g_h):
-        from ..g2048 import native as nv
-
-        u, wb, xn, gamma, stats = ctx.saved_tensors
-        p_drop, seed = ctx.meta
-        T = xn.numel() // 256
-        dx = torch.empty(xn.shape, dtype=torch.float32, device=xn.device)
-        da = torch.empty(xn.shape, dtype=torch.bfloat16, device=xn.device)
-        dparams = torch.empty((3, 256), dtype=torch.float32, device=xn.device)
-        if g_h is None:
-            g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
-        nv.add_ln_bwd(xn.data_ptr(), 256, None if g_x is None else g_x.contiguous(), g_h.contiguous(), stats[0], stats[1],
-                      gamma, dx, da, dparams, T, p_drop, *seed)
-        with torch.autocast("cuda", enabled=False):
-            da2, u2 = da.view(T, 256), u.reshape(T, -1)
-            du = None
-            if ctx.needs_input_grad[0]:
-                du = _hip_linear(da2, ctx.wbT) if ctx.wbT is not None else None
-                du = (da2 @ wb if du is None else du).view(u.shape)
-            dw = _dweight(da2, u2)
-        return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None
-
-
-class _LinearReluDropout(torch.autograd.Function):
-    """``dropout(relu(Linear(h)))`` (linear1 of the feed-forward block): the activation is one kernel each way
-    (``g2048_relu_dropout_fwd/bwd``), only the OUTPUT is saved (it is non-zero exactly where the unit was active and
-    kept), and the backward kernel also yields the bias gradient."""
-
-    @staticmethod
-    def forward(ctx, h, weight, bias, wb, bb, p_drop):
-        from ..g2048 import native as nv
-
-        with torch.autocast("cuda", enabled=False):
-            z = _hip_linear(h.reshape(-1, h.shape[-1]), wb, bias)
-            z = F.linear(h, wb, bb) if z is None else z.view(*h.shape[:-1], wb.shape[0])
-        y = torch.empty_like(z)
-        nv.relu_dropout_fwd(z, y, p_drop, *_seed_pair(z, p_drop))
-        ctx.save_for_backward(h, wb, y)
-        ctx.p_drop = p_drop
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        from ..g2048 import native as nv
-
-        h, wb, y = ctx.saved_tensors
-        dz = torch.empty_like(y)
-        db = torch.empty(y.shape[-1], dtype=torch.float32, device=y.device)
-        nv.relu_dropout_bwd(dy.contiguous(), y, dz, db, ctx.p_drop)
-        with torch.autocast("cuda", enabled=False):
-            dz2, h2 = dz.view(-1, dz.shape[-1]), h.reshape(-1, h.shape[-1])
-            dh = (dz2 @ wb).view(h.shape) if ctx.needs_input_grad[0] else None
-            dw = _dweight(dz2, h2)
-        return dh, dw, db, None, None, None
-
-
-def _fused_norm_ok(x: torch.Tensor, a) -> bool:
-    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and torch.is_grad_enabled()
-            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
-            and (a is None or a.dtype == torch.bfloat16))
-
-
-def _add_norm(x: torch.Tensor, a, norm: nn.LayerNorm, p: float, training: bool):
-    """(x + dropout(a), LayerNorm(x + dropout(a))); ``a`` None: (x, LayerNorm(x))."""
-    if _fused_norm_ok(x, a):
-        x_new, h = _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, p if training else 0.0)
-        return (x if a is None else x_new), h
-    if a is not None:
-        x = x + F.dropout(a, p, training)
-    return x, F.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)
-
-
-class _EmbedBoards(torch.autograd.Function):
-    """Packed boards u8 [M, 16] -> token matrix f32 [M, 17, 256]: CLS row + dropout(embedding + positional code), one
-    gather kernel (``g2048_embed_fwd``); the backward is a segmented sum by cell value (``g2048_embed_bwd``) instead of
-    a one-hot^T x gradient GEMM whose reduction runs over every token of the minibatch.
-    emb_weight: the bias-free input Linear's weight [256, 31]; pe f32 [16, 256]; cls [1, 1, 256]."""
-
-    @staticmethod
-    def forward(ctx, boards, emb_weight, pe, cls, p_drop):
-        from ..g2048 import native as nv
-
-        boards = boards.contiguous()
-        M = boards.shape[0]
-        wt = emb_weight.detach().float().t().contiguous()
-        x0 = torch.empty((M, 17, 256), dtype=torch.float32, device=boards.device)
-        seed = _seed_pair(x0, p_drop)
-        nv.embed_fwd(boards, wt, pe, cls.detach().float().reshape(256).contiguous(), x0, p_drop, *seed)
-        ctx.save_for_backward(boards)
-        ctx.meta = (p_drop, seed, emb_weight.dtype, cls.dtype)
-        return x0
-
-    @staticmethod
-    def backward(ctx, g):
-        from ..g2048 import native as nv
-
-        (boards,) = ctx.saved_tensors
-        p_drop, seed, w_dtype, c_dtype = ctx.meta
-        out = torch.empty((32, 256), dtype=torch.float32, device=g.device)
-        nv.embed_bwd(boards, g.contiguous(), out, p_drop, *seed)
-        return None, out[:31].t().to(w_dtype), None, out[31].view(1, 1, 256).to(c_dtype), None
-
-
-def _fused_attention_ok(t: torch.Tensor, S: int, head_dim: int) -> bool:
-    return (t.is_cuda and t.dtype == torch.bfloat16 and S == 17 and head_dim == 32 and torch.is_grad_enabled()
-            and t.requires_grad)
-
-
-def _train_bf16(t: torch.Tensor, weight: torch.Tensor) -> bool:
-    """The update path: HIP device, gradients wanted, bf16 autocast."""
-    return (t.is_cuda and torch.is_grad_enabled() and weight.requires_grad and torch.is_autocast_enabled()
-            and torch.get_autocast_dtype("cuda") == torch.bfloat16)
-
-
-def _linear(x: torch.Tensor, weight: torch.Tensor, bias, wb=None, bb=None) -> torch.Tensor:
-    if _train_bf16(x, weight):
-        return _LinearSplitK.apply(x, weight, bias, wb, bb)
-    return F.linear(x, weight, bias)
+from .hip_ops import (Bf16Shadow, _AddLayerNorm, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
+                      _LinearAddLayerNorm, _LinearReluDropout, _LinearSplitK, _add_norm, _fused_attention_ok, _fused_norm_ok,
+                      _linear, _train_bf16, graph_seed_state)
 
 
 def get_emb(sin_inp: torch.Tensor) -> torch.Tensor:

@@ -204,7 +204,7 @@ def test_small_attention_kernels_match_sdpa(dev):
     SDPA's own bf16 path, packed and CLS-row variants, odd batch sizes; dropout keeps the expectation."""
     import torch.nn.functional as F
 
-    from src.ppo.transformer_encoder import _AttnCls, _AttnPacked
+    from src.ppo.hip_ops import _AttnCls, _AttnPacked
 
     H, hd, S = 8, 32, 17
     rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
@@ -247,7 +247,7 @@ def test_fused_add_layernorm_matches_torch(dev):
     elements are scaled by 1/(1-p), the mask differs per call and the backward uses the forward's mask."""
     import torch.nn.functional as F
 
-    from src.ppo.transformer_encoder import _AddLayerNorm
+    from src.ppo.hip_ops import _AddLayerNorm
 
     rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
     torch.manual_seed(1)
@@ -364,7 +364,7 @@ def test_hip_graph_update_matches_eager(dev, tmp_path):
 def test_hip_graph_dropout_draws_new_masks_per_replay(dev):
     """Dropout launches captured in a hipGraph read graph_seed_state at run time: each replay (after the word moved)
     draws a new mask, the backward reuses the forward's mask, and call sites inside one graph differ."""
-    from src.ppo.transformer_encoder import _AddLayerNorm, _AttnPacked, graph_seed_state
+    from src.ppo.hip_ops import _AddLayerNorm, _AttnPacked, graph_seed_state
 
     torch.manual_seed(3)
     x = torch.zeros(256, 17, 256, device=dev)
@@ -490,7 +490,7 @@ def test_fused_linear_blocks_match_torch(dev):
     the strided [B, 1, 256] residual slice of the CLS-only layer."""
     import torch.nn.functional as F
 
-    from src.ppo.transformer_encoder import _LinearAddLayerNorm, _LinearReluDropout
+    from src.ppo.hip_ops import _LinearAddLayerNorm, _LinearReluDropout
 
     rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
     torch.manual_seed(11)
@@ -568,7 +568,7 @@ def test_embed_boards_matches_torch(dev):
     """g2048_embed_fwd/bwd (gather + segmented sum) vs one-hot Linear + positional add + CLS concat in PyTorch: tokens and
     the gradients of the embedding weight and the CLS token; with dropout only board tokens are dropped, the backward
     reuses the mask, and the sums are bit-reproducible."""
-    from src.ppo.transformer_encoder import _EmbedBoards
+    from src.ppo.hip_ops import _EmbedBoards
 
     torch.manual_seed(17)
     for M in (1, 5, 2048, 2049):

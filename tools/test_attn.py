@@ -2,7 +2,7 @@ import sys, os, time
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "2048-ppo-agent_amd")); sys.path.insert(0, ROOT)
 import torch, torch.nn.functional as F
-from src.ppo.transformer_encoder import _AttnPacked, _AttnCls
+from src.ppo.hip_ops import _AttnPacked, _AttnCls
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 H, hd, S = 8, 32, 17
 def ref_packed(qkv):
