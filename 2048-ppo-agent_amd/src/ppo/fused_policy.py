@@ -58,6 +58,9 @@ class FusedPolicy:
                   l.norm2.bias, l.linear1.bias, l.linear2.bias]
         self.weights = torch.cat([x.detach().reshape(-1).to(torch.bfloat16) for x in w]).contiguous()
         self.params = torch.cat([x.detach().reshape(-1).float() for x in p]).contiguous()
+        # actor / critic heads: bf16 copies made once per refresh (autocast would re-cast all of them at every lock-step)
+        self.heads = [[(m.weight.detach().to(torch.bfloat16), None if m.bias is None else m.bias.detach().to(torch.bfloat16))
+                       for m in head if isinstance(m, torch.nn.Linear)] for head in (a.actor, a.critic)]
         self.n_layers = len(t.encoder.layers)
 
     # from this many boards on, the last layer runs CLS-only in a second kernel (g2048_policy_encoder with a workspace):
@@ -86,8 +89,13 @@ class FusedPolicy:
     @torch.no_grad()
     def __call__(self, boards: torch.Tensor):
         """boards u8 [B, 16] -> (logits f32 [B, 4] (unmasked), values f32 [B])."""
-        feats = self.features(boards)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            logits = self.agent.actor(feats)
-            values = self.agent.critic(feats)
-        return logits.float(), values.float().reshape(-1)
+        feats = self.features(boards).to(torch.bfloat16)
+        outs = []
+        for layers in self.heads:  # Linear-ReLU-Linear-ReLU-Linear in bf16, what autocast computes
+            x = feats
+            for i, (w, b) in enumerate(layers):
+                x = torch.nn.functional.linear(x, w, b)
+                if i + 1 < len(layers):
+                    x = torch.relu_(x)
+            outs.append(x)
+        return outs[0].float(), outs[1].float().reshape(-1)
