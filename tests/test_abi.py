@@ -48,6 +48,31 @@ def test_invalid_arguments_return_einval_without_touching_a_device():
     assert lib.g2048_gae_flat(None, None, None, None, None, 0, 0.99, 0.95, None) == -1
     key = np.zeros(2, np.uint32)
     assert lib.g2048_chain_keys(key.ctypes.data, None, 3, 1) == -1
+    # the policy-network entry points validate before they launch: null pointers, bad shapes, misalignment
+    a = 1 << 20  # a fake, 16-byte aligned "device address": must be rejected on shape grounds before any use
+    assert lib.g2048_policy_encoder(None, None, None, None, None, 4, None, 8, None, None) == -1
+    assert lib.g2048_policy_encoder(a, a, a, a, a, 0, a, 8, None, None) == -1          # no layers
+    assert lib.g2048_policy_encoder(a, a, a, a + 2, a, 4, a, 8, None, None) == -1      # weights not 16-byte aligned
+    assert lib.g2048_policy_encoder_workspace_bytes(7) == 7 * (2 * 8 * 17 * 32 * 2 + 1024)
+    assert lib.g2048_attn_fwd(None, None, None, None, None, 4, 8, 17, 0, 0, 0, 0, 0, 0, 1.0, 0.0, 0, None, None) == -1
+    assert lib.g2048_attn_fwd(a, a, a, a, a, 4, 8, 5, 13056, 768, 13056, 768, 13056, 768, 1.0, 0.0, 0, None, None) == -1  # Sq
+    assert lib.g2048_add_ln_fwd(a, 256, None, a, a, None, a, a, a, 0, 1e-5, 0.0, 0, None, None) == -1   # T = 0
+    assert lib.g2048_add_ln_fwd(a, 256, a, a, a, None, a, a, a, 4, 1e-5, 0.0, 0, None, None) == -1      # a without x_new
+    assert lib.g2048_add_ln_fwd(a, 255, None, a, a, None, a, a, a, 4, 1e-5, 0.0, 0, None, None) == -1   # row stride % 4
+    assert lib.g2048_add_ln_bwd(a, 256, None, a, a, a, a, a, None, a, None, 4, 0.0, 0, None, None) == -1  # no workspace
+    assert lib.g2048_add_ln_bwd_workspace_floats(65) == 2 * 3 * 256
+    assert lib.g2048_colsum(a, 1, 6, 4, 6, a, a, None) == -1                                  # N not a multiple of 4
+    assert lib.g2048_colsum(a, 1, 2048, 4, 2048, a, a, None) == -1                            # N > 1024
+    assert lib.g2048_relu_dropout_fwd(a, a, 4, 12, 0.1, 0, None, None) == -1                  # F not a multiple of 8
+    assert lib.g2048_relu_dropout_fwd(a, a, 4, 16, 1.0, 0, None, None) == -1                  # p_drop = 1
+    assert lib.g2048_relu_dropout_bwd_workspace_floats(65, 1024) == 2 * 1024
+    assert lib.g2048_linear_bf16(a, 256, a, 256, None, a, 256, 8, 200, 256, None) == -1       # K not a multiple of 128
+    assert lib.g2048_linear_bf16(a, 128, a, 256, None, a, 256, 8, 256, 256, None) == -1       # ldx < K
+    assert lib.g2048_embed_fwd(None, a, a, a, a, 4, 0.0, 0, None, None) == -1
+    assert lib.g2048_embed_bwd(a, a, a, None, 4, 0.0, 0, None, None) == -1
+    assert lib.g2048_embed_bwd_workspace_floats(4) == 256 * 32 * 256
+    assert lib.g2048_ppo_loss(a, 0, a, 0, a, None, a, a, a, 0, 0.2, 0.5, 0.01, a, a, a, a, None) == -1   # M = 0
+    assert lib.g2048_gather_minibatch(a, 4, 0, a, a, a, a, a, a, a, a, a, a, a, a, None) == -1           # empty buffer
 
 
 def test_product_fails_loudly_without_gpu():
