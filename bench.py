@@ -271,6 +271,19 @@ def main():
         **({"DRYRUN": "all ranks shared one GPU over gloo: control-flow rehearsal, not a measurement"} if dryrun else {}),
         "update_minibatches_per_step": trainer.total_update_steps // max(args.steps + args.warmup, 1),
     }
+    if rank == 0 and args.workload == "transformer65536":
+        # the update as a whole: forward + backward of the policy over one minibatch = 3 x the forward FLOPs the "cls"
+        # reduction needs (same accounting as policy_encoder), against the time a minibatch takes end to end
+        full = 17 * 2 * (256 * 768 + 256 * 256 + 2 * 256 * 1024) + 8 * 2 * 2 * 17 * 17 * 32
+        last = 17 * 2 * 256 * 512 + 2 * (256 * 256 + 256 * 256 + 2 * 256 * 1024) + 8 * 2 * 2 * 17 * 32
+        layers = MODEL_CFG["num_layers"]
+        mb = out["update_minibatches_per_step"]
+        if mb:
+            ms_mb = out["phase_seconds_per_step"]["update_s"] / mb * 1e3
+            tf = 3 * ((layers - 1) * full + last) * args.train_batch / (ms_mb * 1e-3) / 1e12
+            out["update"] = {"ms_per_minibatch": round(ms_mb, 3), "minibatch": args.train_batch,
+                             "algorithmic_TFLOPs": round(tf, 1), "frac_of_bf16_peak": round(tf / 2500.0, 4),
+                             "what": "forward + loss + backward (hipGraph replay) + clip + AdamW per minibatch"}
     if rank == 0:
         us = timed.mean_us()
         if us:
