@@ -117,7 +117,10 @@ class _GraphedFwdBwd:
         self.graph = torch.cuda.CUDAGraph()
         Bf16Shadow.invalidate_all()  # the bf16 weight refresh must be part of the graph
         seed_word = graph_seed_state(dev)  # allocated outside the capture
-        with torch.cuda.graph(self.graph):
+        # thread_local: only this thread's calls are checked during the capture.  Other threads (the RCCL watchdog of a
+        # multi-GPU run polling its events) must not be able to invalidate it; the autograd worker's launches are
+        # captured either way because capture is a property of the stream
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             seed_word.add_(1)  # new dropout masks on every replay (the HIP kernels read it at run time)
             self.out = self._fwd_bwd()
             if trainer._flat_grad is not None:
