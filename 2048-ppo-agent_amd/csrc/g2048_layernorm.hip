@@ -237,23 +237,31 @@ extern "C" int64_t g2048_colsum_workspace_floats(int64_t T, int N) {
 
 extern "C" int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int64_t T, int N, float *workspace, float *out,
                             void *stream) {
-    if (!x || !workspace || !out || T <= 0 || N < CS_VEC || N % CS_VEC || N / CS_VEC > CS_THREADS || row_stride % CS_VEC ||
+    if (!x || !workspace || !out || T <= 0 || N < CS_VEC || N % CS_VEC || row_stride % CS_VEC || row_stride < N ||
         ((uintptr_t)x & (is_bf16 ? 7 : 15)) || ((uintptr_t)workspace & 15))
         return G2048_EINVAL;
-    const int rows_per_pass = CS_THREADS / (N / CS_VEC);
-    int64_t G = (T + rows_per_pass - 1) / rows_per_pass;
-    // at least ~16 rows per workgroup, at most MAX_GROUPS workgroups
-    G = (G + 15) / 16;
-    if (G > G2048_COLSUM_MAX_GROUPS) G = G2048_COLSUM_MAX_GROUPS;
-    if (G < 1) G = 1;
-    if (is_bf16)
-        hipLaunchKernelGGL(k_colsum_partial<true>, dim3((unsigned)G), dim3(CS_THREADS), 0, (hipStream_t)stream, x, row_stride, T, N,
-                           workspace);
-    else
-        hipLaunchKernelGGL(k_colsum_partial<false>, dim3((unsigned)G), dim3(CS_THREADS), 0, (hipStream_t)stream, x, row_stride, T, N,
-                           workspace);
-    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream, workspace, (int)G, N,
-                       out);
+    // wider matrices are summed in column tiles of at most CS_THREADS * CS_VEC (1024) columns, each with its own slice of
+    // the workspace (MAX_GROUPS * tile floats, so the slices of all tiles fit in MAX_GROUPS * N)
+    constexpr int TILE_N = CS_THREADS * CS_VEC;
+    for (int c0 = 0; c0 < N; c0 += TILE_N) {
+        const int n = N - c0 < TILE_N ? N - c0 : TILE_N;
+        const void *xt = is_bf16 ? (const void *)((const uint16_t *)x + c0) : (const void *)((const float *)x + c0);
+        float *ws = workspace + (int64_t)G2048_COLSUM_MAX_GROUPS * c0;
+        const int rows_per_pass = CS_THREADS / (n / CS_VEC);
+        int64_t G = (T + rows_per_pass - 1) / rows_per_pass;
+        // at least ~16 rows per workgroup, at most MAX_GROUPS workgroups
+        G = (G + 15) / 16;
+        if (G > G2048_COLSUM_MAX_GROUPS) G = G2048_COLSUM_MAX_GROUPS;
+        if (G < 1) G = 1;
+        if (is_bf16)
+            hipLaunchKernelGGL(k_colsum_partial<true>, dim3((unsigned)G), dim3(CS_THREADS), 0, (hipStream_t)stream, xt, row_stride, T,
+                               n, ws);
+        else
+            hipLaunchKernelGGL(k_colsum_partial<false>, dim3((unsigned)G), dim3(CS_THREADS), 0, (hipStream_t)stream, xt, row_stride, T,
+                               n, ws);
+        hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((n + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_SLICES), 0,
+                           (hipStream_t)stream, ws, (int)G, n, out + c0);
+    }
     return done();
 }
 
@@ -404,7 +412,7 @@ k_embed_fwd(const uint8_t *__restrict__ boards, const float *__restrict__ wt, co
         if (c == 0) {
             v = reinterpret_cast<const float4 *>(cls)[lane];
         } else {
-            const int e = boards[m * 16 + c - 1];
+            const int e = min((int)boards[m * 16 + c - 1], 30);  // wt has 31 rows; the env never exceeds 17
             const float4 a = reinterpret_cast<const float4 *>(wt + (size_t)e * EMB_D)[lane];
             const float4 b = reinterpret_cast<const float4 *>(pe + (size_t)(c - 1) * EMB_D)[lane];
             v = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
@@ -435,7 +443,7 @@ k_embed_bwd(const uint8_t *__restrict__ boards, const float *__restrict__ dx0, f
     for (int64_t row = r0 + w; row < r1; row += 4) {
         const int64_t m = row / EMB_SEQ;
         const int c = (int)(row - m * EMB_SEQ);
-        const int k = c == 0 ? EMB_CLASSES - 1 : (boards[m * 16 + c - 1] & 31);
+        const int k = c == 0 ? EMB_CLASSES - 1 : min((int)boards[m * 16 + c - 1], 30);
         float4 g = reinterpret_cast<const float4 *>(dx0 + row * EMB_D)[lane];
         if (thr && c != 0) {
             const uint64_t base = (uint64_t)row * EMB_D + 4 * lane;
@@ -481,12 +489,10 @@ extern "C" int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *d
     if (!boards || !dx0 || !dwt_dcls || !workspace || M <= 0 || !(p_drop >= 0.f && p_drop < 1.f) ||
         (((uintptr_t)dx0 | (uintptr_t)dwt_dcls | (uintptr_t)workspace) & 15))
         return G2048_EINVAL;
-    static bool attr_set = false;  // benign race: idempotent
+    // per call, not latched: the attribute is per device, and a latch would be the library's only global state
     const int lds = 4 * EMB_CLASSES * EMB_D * (int)sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_embed_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_embed_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return -(1000 + (int)hipGetLastError());
     const int64_t n_rows = M * EMB_SEQ;
     hipLaunchKernelGGL(k_embed_bwd, dim3(EMB_BLOCKS), dim3(256), lds, (hipStream_t)stream, boards, dx0, workspace, n_rows,
                        1.0f / (1.0f - p_drop), (uint32_t)(p_drop * 16777216.0f), (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);

@@ -181,16 +181,15 @@ extern "C" int g2048_linear_bf16(const void *x, int64_t ldx, const void *weight,
     if (!x || !weight || !y || T <= 0 || K < KC || K % KC || N < NS || N % NS || ldx < K || ldw < K || ldy < N || (ldx & 7) ||
         (ldw & 7) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)bias) & 15))
         return G2048_EINVAL;
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device attribute of the one kernel this call launches: set per call, no latch
+    {
         const int lds = NBUF * CHUNK_BYTES;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_stationary<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_stationary<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+        const void *fn = K <= NBUF * KC ? (bias ? reinterpret_cast<const void *>(k_linear_stationary<true>)
+                                                : reinterpret_cast<const void *>(k_linear_stationary<false>))
+                                        : (bias ? reinterpret_cast<const void *>(k_linear<true>)
+                                                : reinterpret_cast<const void *>(k_linear<false>));
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return -(1000 + (int)hipGetLastError());
     }
     const int64_t n_tiles = (T + TOK - 1) / TOK;
     const int slices = N / NS;

@@ -31,10 +31,24 @@ class FusedPolicy:
         if not supports(agent):
             raise ValueError("agent shape not supported by the fused encoder kernel")
         self.agent = agent
+        self._key = None
         self.refresh()
+
+    def _params_key(self):
+        """Changes whenever a parameter was updated in place (optimizer step, load_state_dict) or re-allocated."""
+        ps = list(self.agent.parameters())
+        return (ps[0].data_ptr(), len(ps), sum(p._version for p in ps))
+
+    def refresh_if_stale(self):
+        """Re-pack when the agent's parameters changed since the last pack: an act_fn kept across optimizer steps
+        (an evaluation callback, user code that reuses one TorchActionFunction as the reference does) must not roll
+        out with the weights of the moment it was built."""
+        if self._params_key() != self._key:
+            self.refresh()
 
     @torch.no_grad()
     def refresh(self):
+        self._key = self._params_key()
         a, t = self.agent, self.agent.transformer
         emb = a.input_embedding.weight.t().float()  # [31, 256]
         pe = t.positional_encoding.flat_table().float()  # [16, 256]
@@ -89,6 +103,7 @@ class FusedPolicy:
     @torch.no_grad()
     def __call__(self, boards: torch.Tensor):
         """boards u8 [B, 16] -> (logits f32 [B, 4] (unmasked), values f32 [B])."""
+        self.refresh_if_stale()
         feats = self.features(boards).to(torch.bfloat16)
         outs = []
         for layers in self.heads:  # Linear-ReLU-Linear-ReLU-Linear in bf16, what autocast computes

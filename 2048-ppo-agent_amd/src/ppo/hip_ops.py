@@ -40,7 +40,10 @@ class Bf16Shadow:
     def __call__(self):
         ps = self.params
         key = (ps[0].data_ptr(), sum(p._version for p in ps))
-        if key != self.key:
+        # while a hipGraph is being captured the copy must be part of the graph whatever the key says: a replay runs no
+        # Python, so a shadow that skipped the copy here (e.g. one created by copy.deepcopy / unpickling, which the
+        # _live registry never saw and invalidate_all() therefore missed) would keep its capture-time weights forever
+        if key != self.key or (ps[0].is_cuda and torch.cuda.is_current_stream_capturing()):
             if self.flat is None or self.flat.device != ps[0].device:
                 offs, n = [], 0
                 for q in ps:
@@ -66,11 +69,16 @@ def _colsum(t: torch.Tensor, out=None) -> torch.Tensor:
     """f32 column sums of a [rows, N] device tensor (bias gradients): ``g2048_colsum`` (fixed summation order and safe
     inside a replayed hipGraph, unlike at::sum's semaphore-based cross-workgroup stage) when the shape allows."""
     N = t.shape[-1]
-    if t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and N % 4 == 0 and N <= 1024 and t.stride(0) % 4 == 0 \
-            and t.dtype in (torch.bfloat16, torch.float32):
+    if t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and N % 4 == 0 and t.stride(0) % 4 == 0 \
+            and t.dtype in (torch.bfloat16, torch.float32) and t.data_ptr() % 16 == 0:
         from ..g2048 import native as nv
 
         return nv.colsum(t, out)
+    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+        # at::sum's cross-workgroup stage yields wrong values when replayed from a hipGraph on this stack (DESIGN.md 3):
+        # refuse to capture it, PPOTrainer._build_graph then falls back to the eager update
+        raise RuntimeError(f"column sum of a {tuple(t.shape)} {t.dtype} tensor (strides {t.stride()}) is outside "
+                           "g2048_colsum's shapes and at::sum must not be captured in a hipGraph")
     if out is None:
         return _sum_f32(t)
     return torch.sum(t, 0, dtype=torch.float32, out=out)
@@ -106,8 +114,7 @@ def _dweight(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """dW = dY^T X in f32 from bf16 operands.  It reduces over every token of the minibatch (34 816 at minibatch 2048)
     into a tiny [out, in] matrix; hipBLASLt runs that as 16-64 workgroups on 256 CUs (177 us per GEMM).  Cutting the
     token axis into 16 slices turns it into a batched GEMM with 16x the workgroups plus an f32 sum of the partials:
-    42 us, 4x faster, and the f32 sum is at least as accurate as the single bf16-output GEMM it replaces
-    (tools/probe_splitk.py)."""
+    42 us, 4x faster, and the f32 sum is at least as accurate as the single bf16-output GEMM it replaces."""
     T, S = x2.shape[0], _LinearSplitK.SLICES
     if T % S == 0 and T // S >= 1024:
         return _sum_f32(torch.bmm(dy2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1)))
@@ -150,25 +157,28 @@ class _LinearSplitK(torch.autograd.Function):
 class _InProjCls(torch.autograd.Function):
     """in_proj of the LAST layer when only the CLS row is wanted: q = h[:, :1] Wq^T + bq, kv = h Wkv^T + bkv, with
     the gradients of the whole in_proj weight and bias assembled in one buffer (slicing the parameter instead costs a
-    zero-fill, a copy and an accumulate per slice in the backward).  h, wb, bb bf16; weight/bias the f32 masters."""
+    zero-fill, a copy and an accumulate per slice in the backward).  h, wb, bb bf16; weight/bias the f32 masters.
+    The CLS rows are first gathered into a contiguous [B, D] matrix (one 1 MB copy at minibatch 2048), so that no GEMM
+    of the update takes the [B, 1, D] view with row stride 17 * D as an operand ("the 02:59 fault")."""
 
     @staticmethod
     def forward(ctx, h, weight, bias, wb, bb):
-        D = h.shape[-1]
-        q = F.linear(h[:, :1], wb[:D], bb[:D])
+        B, S, D = h.shape
+        h_cls = h[:, 0].contiguous()
+        q = F.linear(h_cls, wb[:D], bb[:D]).view(B, 1, D)
         kv = F.linear(h, wb[D:], bb[D:])
-        ctx.save_for_backward(h, wb)
+        ctx.save_for_backward(h, h_cls, wb)
         return q, kv
 
     @staticmethod
     def backward(ctx, dq, dkv):
-        h, wb = ctx.saved_tensors
+        h, h_cls, wb = ctx.saved_tensors
         B, S, D = h.shape
-        dq2, dkv2 = dq.reshape(B, D).contiguous(), dkv.reshape(B * S, 2 * D)
+        dq2, dkv2 = dq.reshape(B, D).contiguous(), dkv.reshape(B * S, 2 * D).contiguous()
         dh = (dkv2 @ wb[D:]).view(B, S, D)
         dh[:, 0] += dq2 @ wb[:D]
         dw = torch.empty((3 * D, D), dtype=torch.float32, device=h.device)
-        dw[:D] = dq2.t() @ h[:, 0]
+        dw[:D] = dq2.t() @ h_cls
         dw[D:] = _dweight(dkv2, h.view(B * S, D))
         db = torch.empty(3 * D, dtype=torch.float32, device=h.device)
         _colsum(dq2, db[:D])

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import contextlib
 import logging
+import os
 from collections import deque
 from typing import Dict, Literal, Optional
 
@@ -161,7 +162,8 @@ class PPOTrainer:
                  value_loss_coef: float = 0.5, entropy_coef: float = 0.01, max_grad_norm: float = 0.5,
                  target_kl: float = 0.01, use_action_mask: bool = False, device: torch.device = torch.device("cpu"),
                  mixed_precision: Optional[Literal["float16", "bfloat16"]] = "bfloat16",
-                 max_samples_per_epoch: int = None, shuffle_on_reset: bool = False, rollout_amp: bool = False,
+                 max_samples_per_epoch: int = None, shuffle_on_reset: bool = False,
+                 rollout_amp: Optional[bool] = None,
                  log_dir: str = "logs", use_hip_graph: Optional[bool] = None):
         self.agent = agent.to(device)
         self.batch_runner = batch_runner
@@ -182,8 +184,14 @@ class PPOTrainer:
             self.scaler, self.amp_dtype = None, None
             if mixed_precision is not None:
                 logger.warning("Mixed precision requested but device is %s; disabled.", self.device.type)
-        # the reference rolls out in fp32; rollout_amp runs the rollout forward under the same autocast dtype
-        self.rollout_amp = rollout_amp and self.use_amp
+        # The reference rolls out in fp32 (torch_action_wrapper.py has no autocast) and that is the default here too.
+        # rollout_amp=True runs the rollout forward in the update's autocast dtype -- for bfloat16 and the reference's
+        # default model shape that is the fused MFMA encoder kernel (g2048_policy_encoder).  The reference's unmodified
+        # run/train_ppo_agent.py cannot pass the extra argument, so None (the default) takes it from the environment:
+        # G2048_ROLLOUT_AMP=1 switches the fast path on for a drop-in run.
+        if rollout_amp is None:
+            rollout_amp = os.environ.get("G2048_ROLLOUT_AMP", "0").strip().lower() in ("1", "true", "yes", "on")
+        self.rollout_amp = bool(rollout_amp) and self.use_amp
 
         opt = configure_bert_optimizers(self.agent, steps=max_steps, **dict(optimizer_param_dict))
         self.optimizer = opt["optimizer"]
@@ -208,6 +216,7 @@ class PPOTrainer:
                              and getattr(self.agent, "hip_graph_safe", False))
         self.use_hip_graph = bool(use_hip_graph) and self.device.type == "cuda"
         self._graphs = {}
+        self.hip_graph_fallback = None  # repr of the exception that made _build_graph drop to the eager update
 
         self.writer = _make_writer(log_dir) if self.rank == 0 else _NullWriter()
         self.total_timesteps = 0
@@ -346,7 +355,9 @@ class PPOTrainer:
         except Exception as e:  # the eager path computes the same thing, only slower: never lose a run
             logger.warning("hipGraph capture of the update failed (%s); continuing in eager mode", e)
             self.use_hip_graph = False
+            self.hip_graph_fallback = repr(e)  # reported by update_policy's metrics and by bench.py
             self._graphs.clear()
+            Bf16Shadow.invalidate_all()  # shadows touched inside the aborted capture were never really copied
             self.optimizer.zero_grad(set_to_none=True)
             return None
         return self._graphs[gkey]
@@ -423,8 +434,13 @@ class PPOTrainer:
             logger.warning("No data in rollout buffer")
             return {}
         data = self.rollout_buffer.device_data(self.device)
-        dataset = PPODataset(data, gamma=self.gamma, lambda_gae=self.lambda_gae,
-                             max_samples_per_epoch=self.max_samples_per_epoch,
+        # the reference draws ONE subset of max_samples_per_epoch from the whole buffer (src/ppo/data_loader.py:73-101);
+        # sharded, every rank draws its 1/world share of it from its own slice of the buffer, so the global number of
+        # samples (and of optimiser steps) per epoch is the single-device one
+        per_rank = self.max_samples_per_epoch
+        if per_rank is not None and self.world > 1:
+            per_rank = -(-int(per_rank) // self.world)
+        dataset = PPODataset(data, gamma=self.gamma, lambda_gae=self.lambda_gae, max_samples_per_epoch=per_rank,
                              shuffle_on_reset=self.shuffle_on_reset, group=self._group)
         batches = DeviceBatches(dataset, batch_size, drop_last=True)
         n_per_epoch = len(batches)
@@ -494,6 +510,9 @@ class PPOTrainer:
                    "kl_divergence": mean_kl, "n_updates": n_updates}
         for k, v in metrics.items():
             self.writer.add_scalar(f"train/{k}", v, self.total_timesteps)
+        # how the minibatches ran: replayed hipGraph (and how many captured layouts) or the eager fallback
+        metrics["hip_graph"] = bool(self.use_hip_graph and self._graphs)
+        metrics["hip_graphs_captured"] = len(self._graphs)
         if self.lr_scheduler is not None:
             self.writer.add_scalar("train/lr", self.lr_scheduler.get_last_lr()[0], self.total_timesteps)
         self.writer.add_scalar("train/total_epochs", self.total_epochs, self.total_timesteps)

@@ -12,7 +12,8 @@
  *     never allocates, frees, copies to the host or synchronises.  Kernels are enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the null stream).  Host-side arguments are marked (host).
  *   - Return value: 0 on success, G2048_EINVAL (-1) for a bad argument, -(1000 + hipError_t) when the
- *     launch itself failed.  Nothing throws.  Re-entrant: no global state.
+ *     launch itself failed.  Nothing throws.  Re-entrant: no global state (kernels that need more than the default
+ *     dynamic-LDS limit set that per-device function attribute on every call instead of latching it).
  *   - boards   u8[B][16]  log2(tile) per cell, row-major, 0 = empty, values <= 30; 16-byte aligned
  *   - masks    u8[B]      bit a = legal_action_mask[a]  (0 left, 1 up, 2 right, 3 down)
  *   - done     u8[B]      terminated flag (0/1)
@@ -195,7 +196,8 @@ int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x
 /* ---- policy network (update): bias gradients ------------------------------------------------------------ */
 
 /* out[c] = sum_r x[r][c] for x bf16 (is_bf16 != 0) or f32 [T][N] with element stride row_stride between rows; f32
- * accumulation in a fixed order (bit-reproducible, safe to replay from a hipGraph).  N a multiple of 4, N <= 1024.
+ * accumulation in a fixed order (bit-reproducible, safe to replay from a hipGraph).  N a multiple of 4 (matrices wider
+ * than 1024 columns are summed in column tiles of 1024), row_stride >= N.
  * The bias gradient of every Linear in the update, and the CLS-token gradient (reference: nn.Linear inside
  * src/ppo/transformer_encoder.py:138-148 and src/ppo/ppo_agent.py:59-86; PyTorch computes it with at::sum).
  * workspace: g2048_colsum_workspace_floats(T, N) floats of scratch. */

@@ -3,6 +3,8 @@
 Imports the reference's pure-torch/numpy modules from /root/reference (read-only; nothing is copied) and
 stores inputs + outputs as data in tests/golden/torch_reference.npz:
   * PPOAgent forward / evaluate_actions for a small fixed state-dict      (src/ppo/ppo_agent.py)
+  * the same + the PPO loss for the DEFAULT model shape (d 256, 8 heads, 4 layers, ff 1024, "cls") with the weights of
+    tests/golden/weights_recipe.py (outputs only: the 15.8 MB state-dict is rebuilt from the recipe by the tests)
   * PPODataset GAE (raw and z-scored)                                     (src/ppo/data_loader.py:103-130,61-67)
   * PPOTrainer._compute_ppo_loss components                               (src/ppo/ppo_trainer.py:251-314)
   * RolloutBuffer.store_batch -> get_buffer_data                          (src/ppo/rollout_buffer.py:128-206)
@@ -143,6 +145,42 @@ for gw, gb in g:
 out["lamb/w0"], out["lamb/b0"] = w0, b0
 out["lamb/gw"], out["lamb/gb"] = np.stack([x[0] for x in g]), np.stack([x[1] for x in g])
 out["lamb/w2"], out["lamb/b2"] = w.detach().numpy(), b.detach().numpy()
+
+# ---- default-shape agent (configs/model/transformer_combined.yaml), weights from weights_recipe -----------------------
+sys.path.insert(0, HERE)
+from weights_recipe import fill_state_dict, sample_boards  # noqa: E402
+
+big = PPOAgent(observation_dim=31, action_dim=4, hidden_dim=512, d_model=256, nhead=8, num_layers=4,
+               dim_feedforward=1024, dropout=0.1, reduction="cls").eval()
+sd = big.state_dict()
+sd.update({k: torch.from_numpy(v) for k, v in fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}).items()})
+big.load_state_dict(sd)
+M = 48
+rng2 = np.random.default_rng(2)  # own stream: the older vectors below stay byte-identical
+bboards = sample_boards(M)
+bobs = torch.nn.functional.one_hot(torch.from_numpy(bboards).long(), 31).float()
+bmask_bits = rng2.integers(1, 16, size=M).astype(np.uint8)
+bmasks = torch.tensor((bmask_bits[:, None] >> np.arange(4)) & 1, dtype=torch.bool)
+bactions = torch.tensor([int(rng2.choice(np.flatnonzero(m))) for m in bmasks.numpy()])
+with torch.no_grad():
+    blogits, bvalues = big(bobs, None)
+    blp, _, bent = big.evaluate_actions(bobs, bactions, bmasks)
+    bfeat = big.transformer(big.input_embedding(bobs), reduction="cls")
+trb = PPOTrainer.__new__(PPOTrainer)
+trb.agent, trb.clip_epsilon, trb.value_loss_coef, trb.entropy_coef, trb.use_action_mask = big, 0.2, 0.5, 0.01, True
+bold = blp + torch.tensor(rng2.normal(0, 0.3, size=M), dtype=torch.float32)
+bold[::6] = blp[::6]
+badv = torch.tensor(rng2.normal(0, 1, size=M), dtype=torch.float32)
+badv[::5] = 0.0
+bret = torch.tensor(rng2.normal(0, 1, size=M), dtype=torch.float32)
+with torch.no_grad():
+    bloss, bpl, bvl, bel, bnlp = trb._compute_ppo_loss(bobs, bactions, bmasks, bold, badv, bret)
+out["default/boards"], out["default/mask_bits"], out["default/actions"] = bboards, bmask_bits, bactions.numpy()
+out["default/features"], out["default/logits"], out["default/values"] = bfeat.numpy(), blogits.numpy(), bvalues.numpy()
+out["default/eval_logp"], out["default/eval_entropy"] = blp.numpy(), bent.numpy()
+out["default/old_logp"], out["default/adv"], out["default/ret"] = bold.numpy(), badv.numpy(), bret.numpy()
+out["default/loss_total"], out["default/loss_policy"], out["default/loss_value"] = bloss.numpy(), bpl.numpy(), bvl.numpy()
+out["default/loss_entropy"], out["default/new_logp"] = bel.numpy(), bnlp.numpy()
 
 np.savez_compressed(os.path.join(HERE, "torch_reference.npz"), **out)
 print("wrote", len(out), "arrays")

@@ -1,0 +1,223 @@
+"""Reference-produced vectors through the HIP kernels of the update, at the reference's DEFAULT model shape.
+
+tests/golden/make_golden_torch.py ran the reference's own PPOAgent / PPOTrainer._compute_ppo_loss (d_model 256, 8 heads,
+4 layers, ff 1024, "cls") on the weights of tests/golden/weights_recipe.py and stored inputs + outputs (``default/*``);
+here the same weights go into this repository's agent on the MI355X and every path that can serve the update or the
+rollout must reproduce them: the fp32 path to 1e-5 (north_star), the bf16 HIP paths to the distance bf16 autocast itself
+has from fp32.  Also: the hipGraph-replayed update at the shape bench.py runs against a pure-PyTorch fp32 backward.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from src.g2048 import native as nv
+from src.ppo import PPOAgent, PPOTrainer, RolloutBuffer
+from src.ppo.data_loader import DeviceBatches, PPODataset
+from src.runs import BatchRunner
+from test_host_logic import default_shape_agent
+
+pytestmark = pytest.mark.gpu
+REF = np.load(os.path.join(os.path.dirname(__file__), "golden", "torch_reference.npz"))
+OPTIM = dict(opt_name="adamw", max_lr=4e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, warmup_steps_ratio=0.025,
+             scheduler_names=["constant", "constant"], blacklist_weight_modules=["norm", "embedding"])
+BITS = [1, 2, 4, 8]
+
+
+def _t(key, dev):
+    return torch.from_numpy(REF[key]).to(dev)
+
+
+@pytest.mark.parametrize("which", ["default", "small"])
+def test_ppo_loss_kernel_on_reference_vectors(dev, which):
+    """g2048_ppo_loss (f32 inputs) on the logits / values / actions / masks / old log-probs / advantages / returns of the
+    reference's own _compute_ppo_loss run: new log-probs and the five means within 1e-5 of what the reference returned."""
+    if which == "default":
+        logits, values = _t("default/logits", dev), _t("default/values", dev).reshape(-1)
+        actions, bits = _t("default/actions", dev).to(torch.uint8), _t("default/mask_bits", dev)
+        old, adv, ret = _t("default/old_logp", dev), _t("default/adv", dev), _t("default/ret", dev)
+        want = {k: REF[f"default/{n}"] for k, n in (("pl", "loss_policy"), ("vl", "loss_value"), ("el", "loss_entropy"),
+                                                    ("tot", "loss_total"), ("nlp", "new_logp"))}
+    else:
+        logits, values = _t("agent_mean/logits", dev), _t("agent_mean/values", dev).reshape(-1)
+        actions = _t("agent_mean/actions", dev).to(torch.uint8)
+        bits = (_t("agent_mean/masks", dev).to(torch.uint8) * torch.tensor(BITS, dtype=torch.uint8, device=dev)).sum(-1).to(torch.uint8)
+        old, adv, ret = _t("loss/old_logp", dev), _t("loss/adv", dev), _t("loss/ret", dev)
+        want = {k: REF[f"loss/{n}"] for k, n in (("pl", "policy"), ("vl", "value"), ("el", "entropy"), ("tot", "total"),
+                                                 ("nlp", "new_logp"))}
+    new_lp, sums, dl, dv = nv.ppo_loss(logits.contiguous(), values.contiguous(), actions, bits, old, adv, ret, 0.2, 0.5, 0.01)
+    np.testing.assert_allclose(new_lp.cpu().numpy(), want["nlp"], atol=1e-5, rtol=1e-5)
+    means = [want["pl"].mean(), want["vl"].mean(), want["el"].mean(), float(want["tot"]),
+             float((old.cpu().numpy().astype(np.float64) - want["nlp"]).mean())]
+    np.testing.assert_allclose(sums.cpu().numpy(), np.array(means, np.float32), atol=1e-5, rtol=1e-5)
+    assert torch.isfinite(dl).all() and torch.isfinite(dv).all()
+
+
+def test_default_shape_agent_on_every_device_path(dev):
+    """One state-dict, four ways to evaluate it on the MI355X, against the reference's fp32 outputs:
+    eager fp32 (1e-5), PyTorch bf16 autocast (the yardstick), the HIP bf16 update path (embedding, attention, add+LN,
+    Linear blocks: grad mode + autocast) and the fused rollout encoder k_encoder (both forms)."""
+    from src.ppo.fused_policy import FusedPolicy
+
+    agent = default_shape_agent(dropout=0.0).to(dev)
+    boards, actions = _t("default/boards", dev), _t("default/actions", dev)
+    bits = _t("default/mask_bits", dev)
+    masks = (bits.unsqueeze(-1) & torch.tensor(BITS, dtype=torch.uint8, device=dev)) != 0
+    want = {k: _t(f"default/{k}", dev) for k in ("features", "logits", "values", "eval_logp", "eval_entropy")}
+    agent.eval()
+    with torch.no_grad():
+        feats = agent.features(boards)
+        logits, values = agent(boards, None)
+        lp, _, ent = agent.evaluate_actions(boards, actions, masks)
+    for got, key, atol in ((feats, "features", 3e-5), (logits, "logits", 1e-5), (values, "values", 1e-5),
+                           (lp, "eval_logp", 1e-5), (ent, "eval_entropy", 1e-5)):
+        np.testing.assert_allclose(got.cpu().numpy(), want[key].cpu().numpy(), atol=atol, rtol=1e-5, err_msg=key)
+    # yardstick: what bf16 autocast of the plain PyTorch operators costs (no gradients -> no HIP kernel engages)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        f16 = agent.features(boards).float()
+        l16, v16 = agent(boards, None)
+    base_f = (f16 - want["features"]).abs().mean().item()
+    base_l = (l16.float() - want["logits"]).abs().max().item()
+    assert 0 < base_f < 0.05
+    # the update path: train mode (dropout p = 0), gradients on, bf16 autocast -> every HIP kernel of the update runs
+    agent.train()
+    calls = {"attn": 0, "ln": 0, "embed": 0}
+    orig = (nv.attn_fwd, nv.add_ln_fwd, nv.embed_fwd)
+
+    def counted(name, fn):
+        def wrapper(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapper
+
+    nv.attn_fwd, nv.add_ln_fwd, nv.embed_fwd = (counted("attn", orig[0]), counted("ln", orig[1]), counted("embed", orig[2]))
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            fh = agent.features(boards)
+            lh, vh = agent(boards, None)
+    finally:
+        nv.attn_fwd, nv.add_ln_fwd, nv.embed_fwd = orig
+    assert calls["attn"] == 8 and calls["ln"] >= 16 and calls["embed"] == 2, calls  # 2 forwards x 4 layers
+    err_f = (fh.float() - want["features"]).abs().mean().item()
+    assert err_f < 1.5 * base_f + 1e-4, (err_f, base_f)
+    assert (lh.float() - want["logits"]).abs().max().item() < 2.0 * base_l + 0.02
+    assert (vh.float() - want["values"]).abs().max().item() < 0.05
+    # the rollout encoder
+    agent.eval()
+    fp = FusedPolicy(agent)
+    for split in (False, True):
+        fk = fp.features(boards, split=split)
+        err_k = (fk - want["features"]).abs().mean().item()
+        assert err_k < 1.5 * base_f + 1e-4, (split, err_k, base_f)
+    lk, vk = fp(boards)
+    assert (lk - want["logits"]).abs().max().item() < 2.0 * base_l + 0.03
+    assert (vk - want["values"].reshape(-1)).abs().max().item() < 0.05
+    # a rollout decision is the argmax of logits + Gumbel noise: the greedy action must agree wherever the reference's
+    # top-2 margin exceeds the bf16 noise
+    top2 = want["logits"].topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.1
+    assert (lk.argmax(1)[clear] == want["logits"].argmax(1)[clear]).all()
+
+
+def _fp32_reference_grads(agent, tr, sample):
+    """Pure-PyTorch fp32 backward of the reference loss (_compute_ppo_loss, no autocast, no HIP kernel) on a copy."""
+    ref = copy.deepcopy(agent).float().train()
+    ref.transformer._shadow = None
+    ref._head_shadow = None
+    tr_ref = PPOTrainer.__new__(PPOTrainer)
+    tr_ref.agent, tr_ref.clip_epsilon, tr_ref.value_loss_coef, tr_ref.entropy_coef = ref, tr.clip_epsilon, tr.value_loss_coef, tr.entropy_coef
+    tr_ref.use_action_mask = tr.use_action_mask
+    masks = (sample["masks"].unsqueeze(-1) & torch.tensor(BITS, dtype=torch.uint8, device=sample["masks"].device)) != 0
+    loss = tr_ref._compute_ppo_loss(sample["obs"], sample["actions"].long(), masks, sample["old_lp"], sample["adv"], sample["ret"])[0]
+    loss.backward()
+    return [p.grad.clone() for p in ref.parameters()], loss.item()
+
+
+def test_hip_graph_update_at_bench_shape_matches_fp32_backward(dev, tmp_path):
+    """The shape bench.py runs (4 layers, ff 1024, minibatch 2048; dropout forced to 0 so every path is deterministic):
+    eager HIP-path gradients AND hipGraph-replayed gradients, on batches other than the captured one, against a
+    pure-PyTorch fp32 backward of the reference loss.  Also the regression test of the 02:59 fault's path (CLS-only last
+    layer with packed bf16 shadows at minibatch 2048)."""
+    from src.ppo.ppo_trainer import _GraphedFwdBwd
+
+    torch.manual_seed(0)
+    agent = PPOAgent(d_model=256, nhead=8, num_layers=4, dim_feedforward=1024, hidden_dim=512, dropout=0.0, reduction="cls")
+    tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), dict(OPTIM), max_steps=1000, device=dev,
+                    rollout_amp=True, log_dir=str(tmp_path), max_samples_per_epoch=100000, use_action_mask=True)
+    assert tr.use_hip_graph
+    tr.collect_rollouts(256, 1)
+    M = 2048
+    data = tr.rollout_buffer.device_data(dev)
+    ds = PPODataset(data, gamma=tr.gamma, lambda_gae=tr.lambda_gae, max_samples_per_epoch=4 * M, shuffle_on_reset=False)
+    db = DeviceBatches(ds, M, drop_last=True)
+    samples = [db.gather_packed(idx) for idx in list(db.indices())[:3]]
+    assert len(samples) == 3
+    agent.train()
+    scale = tr.scaler.get_scale()
+    want = [_fp32_reference_grads(agent, tr, s) for s in samples]
+    names = [n for n, _ in agent.named_parameters()]
+
+    def check(tag, i):
+        flat_g = torch.cat([(p.grad / scale).flatten() for p in agent.parameters()])
+        flat_w = torch.cat([g.flatten() for g in want[i][0]])
+        assert torch.isfinite(flat_g).all(), tag
+        cos = torch.nn.functional.cosine_similarity(flat_g, flat_w, dim=0).item()
+        rel = ((flat_g - flat_w).norm() / flat_w.norm()).item()
+        assert cos > 0.995 and rel < 0.1, (tag, i, cos, rel)
+        for n, p, gw in zip(names, agent.parameters(), want[i][0]):
+            # per tensor: bf16 noise relative to the tensor's own gradient norm, floor for near-zero gradients
+            err = ((p.grad / scale - gw).norm() / (gw.norm() + 1e-3 * flat_w.norm())).item()
+            assert err < 0.25, (tag, i, n, err)
+
+    for i, s in enumerate(samples):  # eager HIP path
+        stats, _ = tr._loss_backward(**s)
+        assert abs(stats[3].item() - want[i][1]) < 0.02 * max(1.0, abs(want[i][1]))
+        check("eager", i)
+    gr = _GraphedFwdBwd(tr, M, samples[0])
+    for i in (1, 2, 0, 2):  # replays on other batches than the captured one
+        stats, _ = gr.run(samples[i])
+        assert abs(stats[3].item() - want[i][1]) < 0.02 * max(1.0, abs(want[i][1]))
+        check("graph", i)
+
+
+def test_update_policy_replays_a_graph_at_bench_shape(dev, tmp_path):
+    """update_policy at bench.py's model shape and minibatch with the default dropout: the captured graph must still be in
+    use afterwards (a silent eager fallback would halve the update's throughput) and the parameters stay finite."""
+    torch.manual_seed(1)
+    agent = PPOAgent(d_model=256, nhead=8, num_layers=4, dim_feedforward=1024, hidden_dim=512, dropout=0.1, reduction="cls")
+    tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), dict(OPTIM), max_steps=1000, device=dev,
+                    rollout_amp=True, log_dir=str(tmp_path), max_samples_per_epoch=3 * 2048 + 5, use_action_mask=True,
+                    target_kl=0.25)
+    tr.collect_rollouts(256, 1)
+    before = [p.detach().clone() for p in agent.parameters()]
+    m = tr.update_policy(batch_size=2048, n_epochs=2)
+    assert m["n_updates"] >= 3 and m["hip_graph"] is True and m["hip_graphs_captured"] == 1
+    assert tr.use_hip_graph and tr._graphs and tr.hip_graph_fallback is None
+    assert all(torch.isfinite(p).all() for p in agent.parameters())
+    assert any(not torch.equal(a, b) for a, b in zip(before, agent.parameters()))
+
+
+def test_colsum_wide_and_capture_guard(dev):
+    """g2048_colsum tiles matrices wider than 1024 columns; a shape outside it must refuse to be captured in a hipGraph
+    (at::sum does not survive a replay on this stack) instead of silently producing wrong bias gradients."""
+    from src.ppo.hip_ops import _colsum
+
+    torch.manual_seed(4)
+    for T, N in ((300, 1028), (4097, 1536), (50, 4096)):
+        for dt in (torch.bfloat16, torch.float32):
+            x = torch.randn(T, N, device=dev).to(dt)
+            got = _colsum(x)
+            assert torch.allclose(got.double(), x.double().sum(0), rtol=2e-5, atol=2e-4 * T ** 0.5)
+    odd = torch.randn(64, 6, device=dev)
+    assert torch.allclose(_colsum(odd), odd.sum(0), atol=1e-4)  # eager: at::sum fallback is fine
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _colsum(odd)
+    torch.cuda.current_stream().wait_stream(side)
+    with pytest.raises(RuntimeError, match="must not be captured"):
+        with torch.cuda.graph(g):
+            _colsum(odd)

@@ -186,3 +186,41 @@ def test_history_slices_like_a_list():
     h = _History(maxlen=5)
     h.extend(range(8))
     assert h[-3:] == [5, 6, 7] and h[0] == 3 and len(h) == 5
+
+
+def default_shape_agent(dropout=0.1):
+    """This repository's PPOAgent at the reference's default shape, with the weights of tests/golden/weights_recipe.py
+    (the recipe make_golden_torch.py loaded into the REFERENCE's PPOAgent to produce the ``default/*`` vectors)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from weights_recipe import fill_state_dict
+
+    agent = PPOAgent(observation_dim=31, action_dim=4, hidden_dim=512, d_model=256, nhead=8, num_layers=4,
+                     dim_feedforward=1024, dropout=dropout, reduction="cls").eval()
+    sd = agent.state_dict()
+    sd.update({k: torch.from_numpy(v) for k, v in fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}).items()})
+    agent.load_state_dict(sd)
+    return agent
+
+
+def test_default_shape_agent_and_loss_match_reference():
+    """d_model 256 / 8 heads / 4 layers / ff 1024 / "cls": forward, evaluate_actions and the PPO loss of the torch
+    restatement against vectors the reference's own modules produced for the same (recipe) weights."""
+    agent = default_shape_agent()
+    t = lambda k: torch.from_numpy(REF[f"default/{k}"])
+    boards, bits, actions = t("boards"), t("mask_bits"), t("actions")
+    masks = (bits.unsqueeze(-1) & torch.tensor([1, 2, 4, 8], dtype=torch.uint8)) != 0
+    with torch.no_grad():
+        np.testing.assert_allclose(agent.features(boards).numpy(), REF["default/features"], atol=2e-5, rtol=1e-5)
+        logits, values = agent(boards, None)
+        np.testing.assert_allclose(logits.numpy(), REF["default/logits"], atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(values.numpy(), REF["default/values"], atol=1e-5, rtol=1e-5)
+        lp, _, ent = agent.evaluate_actions(boards, actions, masks)
+        np.testing.assert_allclose(lp.numpy(), REF["default/eval_logp"], atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(ent.numpy(), REF["default/eval_entropy"], atol=1e-5, rtol=1e-5)
+        tr = PPOTrainer.__new__(PPOTrainer)
+        tr.agent, tr.clip_epsilon, tr.value_loss_coef, tr.entropy_coef, tr.use_action_mask = agent, 0.2, 0.5, 0.01, True
+        loss, pl, vl, el, nlp = tr._compute_ppo_loss(boards, actions, masks, t("old_logp"), t("adv"), t("ret"))
+    for got, key in ((loss, "loss_total"), (pl, "loss_policy"), (vl, "loss_value"), (el, "loss_entropy"), (nlp, "new_logp")):
+        np.testing.assert_allclose(got.numpy(), REF[f"default/{key}"], atol=1e-5, rtol=1e-5)
