@@ -62,7 +62,7 @@ def test_invalid_arguments_return_einval_without_touching_a_device():
     assert lib.g2048_add_ln_bwd(a, 256, None, a, a, a, a, a, None, a, None, 4, 0.0, 0, None, None) == -1  # no workspace
     assert lib.g2048_add_ln_bwd_workspace_floats(65) == 2 * 3 * 256
     assert lib.g2048_colsum(a, 1, 6, 4, 6, a, a, None) == -1                                  # N not a multiple of 4
-    assert lib.g2048_colsum(a, 1, 2048, 4, 2048, a, a, None) == -1                            # N > 1024
+    assert lib.g2048_colsum(a, 1, 512, 4, 1024, a, a, None) == -1                             # row stride < N
     assert lib.g2048_relu_dropout_fwd(a, a, 4, 12, 0.1, 0, None, None) == -1                  # F not a multiple of 8
     assert lib.g2048_relu_dropout_fwd(a, a, 4, 16, 1.0, 0, None, None) == -1                  # p_drop = 1
     assert lib.g2048_relu_dropout_bwd_workspace_floats(65, 1024) == 2 * 1024
