@@ -3,30 +3,46 @@
 // Replaces, for rollouts, the PyTorch path of PPOAgent.features() (reference src/ppo/ppo_agent.py:103-106,
 // src/ppo/transformer_encoder.py:150-190: embedding + 2-D positional code + CLS token + L pre-norm encoder
 // layers, "cls" reduction) at the reference's default shape: d_model 256, 8 heads of 32, feed-forward 1024,
-// 17 tokens per board.  One workgroup (4 waves) carries 7 boards = 119 tokens (+9 pad) through ALL layers:
-// the residual stream never leaves registers, the only activations that touch LDS are the per-head Q/K/V/O
-// tiles, weights stream from L2 through LDS, and nothing but the 16-byte boards is read from / the 1 KiB CLS
+// 17 tokens per board.  One workgroup (4 waves, one per SIMD) carries 7 boards = 119 tokens (+9 pad) through ALL
+// layers: the f32 residual stream never leaves registers, the only activations that touch LDS are one head's K and
+// V^T tiles, weights stream L2 -> LDS by LDS-DMA, and nothing but the 16-byte boards is read from / the 1 KiB CLS
 // feature rows written to HBM.
 //
 // Orientation: every GEMM is computed transposed, Y^T[out_feature][token] = W[out][in] . X^T[in][token], with
-// v_mfma_f32_32x32x16_bf16: the A operand is a weight tile (row-major [out][in], exactly nn.Linear's layout),
-// the B operand holds tokens on lanes.  Each wave owns 32 tokens; its residual R^T[256][32] is 8 accumulator
-// tiles (128 VGPRs).  In this orientation LayerNorm is a per-lane reduction over registers (+1 exchange with
-// lane^32), and an accumulator tile is directly the B operand of the next GEMM (LN -> QKV, LN -> FFN1,
-// relu(FFN1) -> FFN2) with the k-order permutation the hardware layout implies (see frag_from_acc).
+// v_mfma_f32_32x32x16_bf16: the A operand is a weight tile (row-major [out][in], nn.Linear's layout), the B operand
+// holds tokens on lanes.  Each wave owns 32 tokens; its residual R^T[256][32] is 8 accumulator tiles (128 registers).
+// LayerNorm is then a per-lane reduction over registers (+1 exchange with lane^32), and an accumulator tile is
+// directly the B operand of the next product (LN -> QKV, LN -> FFN1, relu(FFN1) -> FFN2, Q^T -> scores, P^T -> P.V,
+// O^T -> out-proj) with the k-order permutation the hardware layout implies (frag_from_acc).
+//
+// Attention (per head): Q^T and O^T never leave registers.  Every wave computes K^T (tokens on lanes) and V (operands
+// swapped: tokens on accumulator rows) of its 32 tokens and writes them as 16-byte runs into the workgroup's K
+// [128 keys][32] and V^T [32][128 keys] tiles.  Boards (17 tokens) straddle waves, so a wave scores its 32 queries
+// against a 64-key window of those tiles that covers every board it touches; keys of other boards are masked by one
+// extra MFMA step instead of vector instructions: a one-hot code of the board index, scaled by 16, appended to the
+// reduction dimension adds 256 to every same-board score, which after the max-subtraction leaves exp2(-65) = 0 for
+// every other key.
+//
+// Software pipeline: while the vector ALU runs head h's softmax the matrix pipe runs head h+1's Q/K/V projections;
+// while it packs feed-forward chunk c (ReLU, bf16) the matrix pipe runs chunk c+1's first GEMM.  Weight tiles for the
+// next head / chunk are always in flight behind the current one (two barriers per head, one per feed-forward chunk).
+//
+// Parameter folding (done by the caller when it packs the blobs, see include/g2048.h): LayerNorm's affine is folded
+// into the following Linear (W' = W diag(gamma), b' = b + W beta), the key bias is dropped (it shifts all scores of a
+// query equally) and the value bias moves into the out-proj bias (softmax rows sum to 1).
 //
 // Numerics mirror torch.autocast(bf16): GEMM inputs rounded to bf16, f32 accumulation, f32 residual stream,
 // f32 LayerNorm / softmax statistics.
 //
 // Two-kernel form (when the caller passes a workspace).  Only the CLS row of the LAST layer is read by the "cls"
-// reduction, yet that layer's Q / out-proj / feed-forward weights (1.26 MB) would be streamed for 7 useful tokens per
-// workgroup.  MODE_HEAD runs layers 0..L-2 as described, then only LayerNorm + the K/V projections of layer L-1, and
-// parks K, V (bf16, 17 KB per board) and the CLS residual row in HBM.  MODE_TAIL batches the CLS tokens of 128 boards
-// per workgroup (one board per lane) through the rest of layer L-1: Q projection, attention of that single query
-// over its board's 17 keys in-lane (K/V from HBM), out-proj, feed-forward - the same code with 18x fewer workgroups.
+// reduction.  k_encoder_main<HEAD> runs layers 0..L-2, then only LayerNorm + the K/V projections of layer L-1, and
+// parks K, V (bf16, 17 KB per board) and the CLS residual row in HBM.  k_encoder_tail batches the CLS tokens of 128
+// boards per workgroup (one board per lane) through the rest of layer L-1: Q projection, attention of that single query
+// over its board's 17 keys in-lane (K/V from HBM), out-proj, feed-forward.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
+
+#include <type_traits>
 
 #include "../../include/g2048.h"
 
@@ -36,8 +52,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__constant__ int g_dbg = 0;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int D = 256, NH = 8, HD = 32, FF = 1024, SEQ = 17, NBOARD = 7, NTOK = 128, THREADS = 256;
 constexpr int W_LAYER = 3 * D * D + D * D + FF * D + D * FF;        // bf16 elements per layer
@@ -46,44 +61,17 @@ constexpr int P_LAYER = D + D + 3 * D + D + D + D + FF + D;         // f32 eleme
 constexpr int WO_QKV = 0, WO_O = 3 * D * D, WO_1 = WO_O + D * D, WO_2 = WO_1 + FF * D;
 constexpr int PO_LN1G = 0, PO_LN1B = D, PO_BQKV = 2 * D, PO_BO = 5 * D, PO_LN2G = 6 * D, PO_LN2B = 7 * D,
               PO_B1 = 8 * D, PO_B2 = 8 * D + FF;
-
-// LDS images.
-//  * Weight tiles are filled by LDS-DMA (global_load_lds_dwordx4: every wave-instruction lands 64 x 16 bytes
-//    contiguously, the SOURCE address is per lane), so they are unpadded [rows][K] images whose 16-byte chunks are
-//    XOR-swizzled inside a row: chunk q of row r lives at q ^ swz(r).  With that, the 16 lanes of a ds_read_b128
-//    lane group (16 rows, distinct mod 16) always hit 16 different 16-byte bank slots.
-//  * Tiles written by the kernel itself (Q, K, O: [token][32]; V^T: [32][7 x 32]) use rows padded by 16 bytes.
-constexpr int ST32 = 2 * 32 + 16;
 constexpr int FFC = 64;               // feed-forward hidden units per pipeline stage
-constexpr int VT_COLS = NBOARD * 32;  // V^T keeps every board's 17 keys in its own 32-aligned column slot
-constexpr int STVT = 2 * VT_COLS + 16;
-constexpr int QK_ROWS = NTOK + 32;    // attention units read 32 rows starting at 17*b
 constexpr int TILE = 32 * D * 2;      // bytes of a [32][256] (= [256][32]) bf16 tile: 16 KiB
-
-struct LdsAttn {  // per-head activations; idle during the feed-forward block (then the start hosts a weight tile)
-    char q[QK_ROWS * ST32], k[QK_ROWS * ST32];
-    char vt[HD * STVT];
-    char o[NTOK * ST32];
-};
-struct Lds {
-    // attention block: wq @0, wk @TILE, wv @2 TILE, wo @3 TILE / 4 TILE (alternating heads).  feed-forward: w1[0] @0, w1[1] @2 TILE, w2[0] @4 TILE
-    // (each 2 TILE), w2[1] aliases `act`.
-    char w[6 * TILE];
-    union {
-        LdsAttn a;
-        char w2b[2 * TILE];
-    } act;
-    float gamma[D], beta[D];
-    float bias[FF];
-};
-static_assert(sizeof(LdsAttn) >= 2 * TILE, "attention scratch must be able to host one feed-forward weight tile");
-static_assert(sizeof(Lds) <= 160 * 1024, "LDS budget");
+constexpr float SM_SCALE_LOG2E = 0.17677669529663687f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e)
 
 __device__ __forceinline__ int rowof(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
-// swizzles: CPR = 16-byte chunks per row
+// swizzles: CPR = 16-byte chunks per row; chunk q of row r lives at q ^ swz(r), so that the 16 lanes of a
+// ds_read_b128 lane group (16 rows, distinct mod 16) always hit 16 different 16-byte bank slots
 template <int CPR> __device__ __forceinline__ int swz(int r);
 template <> __device__ __forceinline__ int swz<32>(int r) { return r & 15; }
+template <> __device__ __forceinline__ int swz<16>(int r) { return r & 15; }
 template <> __device__ __forceinline__ int swz<8>(int r) { return (r >> 1) & 7; }
 template <> __device__ __forceinline__ int swz<4>(int r) { return (r >> 2) & 3; }
 
@@ -122,21 +110,17 @@ __device__ __forceinline__ void lane_offsets(LaneOff &o, int r, int h, int w, in
 // ds_read_b128 at lane offset + constant.
 // When the OTHER operand comes out of an accumulator (frag_from_acc) its element j of lane-half h is
 // k = 16ks + 8(j>>2) + 4h + (j&3); tiles read against it are stored with the columns of every group of 16 in the
-// order KPERM = [0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15] (the host packs the weights that way, the kernel writes V^T
-// that way), so the same contiguous read delivers exactly those k.
+// order KPERM = [0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15] (the host packs the weights that way, the kernel writes K and
+// V^T that way), so the same contiguous read delivers exactly those k.
 template <int CPR>
 __device__ __forceinline__ bf16x8 load_w(const char *tile, const LaneOff &o, int mt, int ks) {
     if (CPR == 32) return *reinterpret_cast<const bf16x8 *>(tile + o.a256[ks & 7] + (ks >> 3) * 256 + mt * 32 * 512);
     if (CPR == 8) return *reinterpret_cast<const bf16x8 *>(tile + o.a64[ks] + mt * 32 * 128);
     return *reinterpret_cast<const bf16x8 *>(tile + o.a32[ks] + mt * 32 * 64);
 }
-// same from a padded kernel-written tile
+// same from a padded kernel-written tile (tail kernel)
 __device__ __forceinline__ bf16x8 load_p(const char *row, int ks, int h) {
     return *reinterpret_cast<const bf16x8 *>(row + 2 * (16 * ks + 8 * h));
-}
-__device__ __forceinline__ int kperm_pos(int k) {  // storage column of logical k under KPERM
-    const int p = k & 15, q = (p & 3) | ((p & 4) << 1) | ((p & 8) >> 1);
-    return (k & ~15) | q;
 }
 
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -149,376 +133,716 @@ __device__ __forceinline__ void frag_from_acc(const f32x16 &x, bf16x8 out[2]) {
     for (int s = 0; s < 2; ++s)
         for (int j = 0; j < 8; ++j) out[s][j] = (__bf16)x[8 * s + j];
 }
+// the same with ReLU: max(x, 0) on the packed bf16 pairs as 16-bit integers (negative floats are negative integers,
+// -0.0 included), one v_pk_max_i16 per two elements
+__device__ __forceinline__ void relu_frag_from_acc(const f32x16 &x, bf16x8 out[2]) {
+    frag_from_acc(x, out);
+    for (int s = 0; s < 2; ++s) {
+        s16x2 *p = reinterpret_cast<s16x2 *>(&out[s]);
+        const s16x2 zero = {0, 0};
+        for (int q = 0; q < 4; ++q) p[q] = __builtin_elementwise_max(p[q], zero);
+    }
+}
 
-// acc += W_tile[32 rows from `row`][16*NK] . B.  The operand reads are ordinary loads here; pipe_mfma() after a group
-// of these calls (one basic block) tells the scheduler to keep DEPTH reads in flight ahead of a back-to-back MFMA
-// chain: with one wave per SIMD nothing else hides the ~100-cycle LDS latency, and left alone the compiler emits
-// read -> wait -> MFMA per k-step.
-template <int CPR, int NK>
+// acc[i] = b[rowof(i, h)] for a 32-row tile: the bias enters through the accumulator's initial value (4 broadcast
+// ds_read_b128) instead of 16 vector adds after the MFMA chain
+__device__ __forceinline__ f32x16 bias_tile(const float *b32, int h) {
+    f32x16 a;
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(b32 + 8 * g + 4 * h);
+        for (int q = 0; q < 4; ++q) a[4 * g + q] = v[q];
+    }
+    return a;
+}
+
+// acc += W_tile[32 rows of M-tile mt][16*NK] . B  (SWAP: acc += B^T . W_tile^T, i.e. tokens on the accumulator's rows).
+// The operand reads are ordinary loads here; pipe_mfma() after a group of these calls (one basic block) tells the
+// scheduler to keep DEPTH reads in flight ahead of a back-to-back MFMA chain: with one wave per SIMD nothing else
+// hides the ~100-cycle LDS latency, and left alone the compiler emits read -> wait -> MFMA per k-step.
+template <int CPR, int NK, bool SWAP = false>
 __device__ __forceinline__ f32x16 gemm_tile(const char *tile, const LaneOff &o, int mt, const bf16x8 *b, f32x16 acc) {
     bf16x8 a[NK];
     for (int ks = 0; ks < NK; ++ks) a[ks] = load_w<CPR>(tile, o, mt, ks);
-    for (int ks = 0; ks < NK; ++ks) acc = mfma(a[ks], b[ks], acc);
+    for (int ks = 0; ks < NK; ++ks) acc = SWAP ? mfma(b[ks], a[ks], acc) : mfma(a[ks], b[ks], acc);
     return acc;
 }
-template <int TOTAL, int DEPTH = 8>
+// Scheduling recipe for one region (the code between two sched_fence() / barriers): NM MFMAs fed by NM operand reads
+// (+ EXTRA reads issued up front: bias tiles), DEPTH reads in flight ahead of a back-to-back MFMA chain, and behind each
+// of the first NV MFMAs VALU_PER plain vector instructions and TRANS_PER transcendental ones (the softmax / packing work
+// that runs in the matrix pipe's shadow).  Group masks: 0x008 MFMA, 0x100 DS read, 0x002 VALU, 0x400 TRANS.
+template <int NM, int EXTRA = 0, int NV = 0, int VALU_PER = 0, int TRANS_PER = 0, int DEPTH = 8>
 __device__ __forceinline__ void pipe_mfma() {
-    __builtin_amdgcn_sched_group_barrier(0x100, DEPTH, 0);
-    for (int i = 0; i < TOTAL - DEPTH; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x100, DEPTH + EXTRA, 0);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i < NM - DEPTH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i < NV && VALU_PER) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);
+        if (i < NV && TRANS_PER) __builtin_amdgcn_sched_group_barrier(0x400, TRANS_PER, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, DEPTH, 0);
 }
+// compile-time loop: f(integral_constant<int, I>) for I = I0..N-1, every index a constant (register arrays stay registers,
+// `if constexpr` on the step number prunes the body per step)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// nothing is scheduled across this point
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // LDS-DMA of a [rows][CPR*8] bf16 tile (global row stride ld elements) into a swizzled LDS image.  Asynchronous:
-// complete for this wave after s_waitcnt vmcnt(0), for the other waves after the following barrier.
-// Source address = uniform tile base + uniform per-instruction step + per-lane offset from LaneOff.
+// complete for this wave after s_waitcnt vmcnt(..), for the other waves after the following barrier.
+// `buffer_load_dwordx4 ... offen lds`: the weight blob is one buffer resource (SGPRs), the tile base + per-instruction
+// step is the scalar offset, the per-lane part (LaneOff) the vector offset: no vector address arithmetic per fetch.
+// rows * CPR / 256 wave-instructions per wave: 4 per 16 KiB.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 template <int CPR>
-__device__ __forceinline__ void dma_tile(char *dst, const __bf16 *src, int ld, int rows, const LaneOff &o, int w) {
-    if (g_dbg & 1) return;  // timing-only switch (development): no weight stream, outputs are garbage
+__device__ __forceinline__ void dma_tile(char *dst, rsrc_t blob, unsigned src_byte, int ld, int rows, const LaneOff &o, int w) {
     const int n_inst = rows * CPR / (64 * 4);       // wave-instructions per wave
     const int rows_per_inst = 4 * 64 / CPR;         // rows covered by one instruction of all four waves
-    const char *base = reinterpret_cast<const char *>(src);
     for (int t = 0; t < n_inst; ++t) {
         const unsigned lane_off = CPR == 32 ? o.s256[t & 1] : (CPR == 8 ? o.s64 : o.s32);
-        const char *g = base + (size_t)t * rows_per_inst * ld * 2 + lane_off;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)(dst + (t * 4 + w) * 1024), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(blob, (__attribute__((address_space(3))) void *)(dst + (t * 4 + w) * 1024), 16,
+                                                 (int)lane_off, (int)(src_byte + (unsigned)(t * rows_per_inst * ld * 2)), 0, 0);
     }
 }
-__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// all but the N youngest vector-memory operations of this wave have completed (they retire in issue order)
+template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void dma_wait_all() { dma_wait<0>(); }
 
 __device__ __forceinline__ void stage_f32(float *dst, const float *src, int n, int tid) {
     for (int i = tid; i < n; i += THREADS) dst[i] = src[i];
 }
 
-// LayerNorm over the 256 features of each token (lane = token; this lane holds rows 4h + ... of every tile, the
-// partner lane^32 the others) -> bf16 B-operand fragments for a K = 256 product (k-step 2j + s).
-__device__ __forceinline__ void layer_norm(const f32x16 r[8], const float *gamma, const float *beta, int h,
-                                           bf16x8 out[16]) {
-    float s = 0.f;
-    for (int j = 0; j < 8; ++j)
-        for (int i = 0; i < 16; ++i) s += r[j][i];
-    s += __shfl_xor(s, 32);
-    const float mean = s * (1.0f / D);
-    float v = 0.f;
-    for (int j = 0; j < 8; ++j)
-        for (int i = 0; i < 16; ++i) {
-            const float d = r[j][i] - mean;
-            v += d * d;
-        }
-    v += __shfl_xor(v, 32);
-    const float rstd = rsqrtf(v * (1.0f / D) + 1e-5f);
-    for (int j = 0; j < 8; ++j)
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 32 * j + 8 * g + 4 * h;
-            const f32x4 gm = *reinterpret_cast<const f32x4 *>(gamma + f0);
-            const f32x4 bt = *reinterpret_cast<const f32x4 *>(beta + f0);
-            for (int q = 0; q < 4; ++q) {
-                const int i = 4 * g + q;
-                const float y = (r[j][i] - mean) * rstd * gm[q] + bt[q];
-                out[2 * j + (i >> 3)][i & 7] = (__bf16)y;
-            }
-        }
+// Park an MFMA operand fragment in the accumulator half of the register file (MFMA reads A/B operands from either half).
+// With one wave per SIMD the 256 architectural VGPRs are the scarce half: the normalised activations (64 registers) and
+// the masking constants would otherwise crowd out the operand prefetch buffers of the MFMA chains.
+__device__ __forceinline__ void park_in_agpr(bf16x8 &x) { asm volatile("" : "+a"(x)); }
+
+// lanes l and l^32 hold the two halves of a token's reduction: one v_permlane32_swap gives both lanes both halves
+__device__ __forceinline__ float xhalf_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xhalf_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-constexpr int MODE_FULL = 0, MODE_HEAD = 1, MODE_TAIL = 2;
+// Normalisation over the 256 features of each token (lane = token; this lane holds rows 4h + ... of every tile, the
+// partner lane^32 the others) -> bf16 B-operand fragments for a K = 256 product (k-step 2j + s).  The affine part
+// lives in the following Linear's packed weights.  One pass over the registers for both moments.
+__device__ __forceinline__ void layer_norm(const f32x16 r[8], bf16x8 out[16]) {
+    float s = 0.f, ss = 0.f;
+    for (int j = 0; j < 8; ++j)
+        for (int i = 0; i < 16; ++i) {
+            s += r[j][i];
+            ss = __builtin_fmaf(r[j][i], r[j][i], ss);
+        }
+    s = xhalf_sum(s);
+    ss = xhalf_sum(ss);
+    const float mean = s * (1.0f / D);
+    const float var = fmaxf(__builtin_fmaf(-mean, mean, ss * (1.0f / D)), 0.0f);
+    const float rstd = rsqrtf(var + 1e-5f), shift = -mean * rstd;
+    for (int j = 0; j < 8; ++j)
+        for (int i = 0; i < 16; ++i) out[2 * j + (i >> 3)][i & 7] = (__bf16)__builtin_fmaf(r[j][i], rstd, shift);
+    for (int k = 0; k < 16; ++k) park_in_agpr(out[k]);
+}
+
+constexpr int MODE_FULL = 0, MODE_HEAD = 1;
 // HBM workspace of the two-kernel form, per board: K and V of the last layer as [head][key][lane half][16] bf16 (the 16
 // values a lane half holds for one (token, head) are contiguous), then the CLS residual row (256 f32).
 constexpr int64_t KV_ELEMS = (int64_t)NH * SEQ * HD;  // per board, per K or V
 
+// ---------------------------------------------------------------------------------------------------------------------
+// main kernel
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS map (bytes).  Attention block: in_proj tiles of two heads, the out-proj slice of one, one head's K and V^T.
+// Feed-forward block: linear1 / linear2 slices of two 64-unit chunks each, over the same 128 KiB.
+constexpr int L_WQKV = 0;                 // [2][3 TILE]: q, k, v tile of head (h & 1)
+constexpr int L_WO = 6 * TILE;            // [256][32] slice of out_proj.weight
+constexpr int L_K = 7 * TILE;             // K   [128 keys][32 d]   bf16, 64-byte rows, chunks swizzled (CPR 4)
+constexpr int L_VT = 7 * TILE + TILE / 2; // V^T [32 d][128 keys]   bf16, 256-byte rows, chunks swizzled (CPR 16)
+constexpr int L_W1 = 0;                   // [2][2 TILE]: [64][256] slice of linear1.weight of chunk (c & 1)
+constexpr int L_W2 = 4 * TILE;            // [2][2 TILE]: [256][64] slice of linear2.weight of chunk (c & 1)
+struct LdsMain {
+    char w[8 * TILE];
+    float bq[D], bo[D], b1[FF], b2[D];
+};
+static_assert(sizeof(LdsMain) <= 160 * 1024, "LDS budget");
+
 template <int MODE>
 __global__ void __launch_bounds__(THREADS, 1)
-k_encoder(const uint8_t *__restrict__ boards, const float *__restrict__ table, const float *__restrict__ cls,
-          const __bf16 *__restrict__ wblob, const float *__restrict__ pblob, int n_layers,
-          float *__restrict__ features, int64_t B, __bf16 *__restrict__ ws_k, __bf16 *__restrict__ ws_v,
-          float *__restrict__ ws_r) {
+k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ table, const float *__restrict__ cls,
+               const __bf16 *__restrict__ wblob, const float *__restrict__ pblob, int n_layers,
+               float *__restrict__ features, int64_t B, __bf16 *__restrict__ ws_k, __bf16 *__restrict__ ws_v,
+               float *__restrict__ ws_r) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    Lds &L = *reinterpret_cast<Lds *>(smem);
-    LdsAttn &A = L.act.a;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int64_t board0 = (int64_t)blockIdx.x * (MODE == MODE_TAIL ? NTOK : NBOARD);
-    char *const wq = L.w, *const wk = L.w + TILE, *const wv = L.w + 2 * TILE;
+    LdsMain &L = *reinterpret_cast<LdsMain *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t board0 = (int64_t)blockIdx.x * NBOARD;
     LaneOff lo;
     lane_offsets(lo, r, h, w, lane);
 
-    // ---- this lane's token.  MODE_TAIL: token = the CLS token of board board0 + tok.
+    // ---- this lane's token
     const int tok = 32 * w + r;                     // 0..127 inside the tile
-    const int tb = MODE == MODE_TAIL ? tok : tok / SEQ;         // board in tile
-    const int tc = MODE == MODE_TAIL ? 0 : tok - tb * SEQ;      // position (0 = CLS)
-    const bool tok_real = MODE == MODE_TAIL ? true : tb < NBOARD;
-    const bool tok_valid = tok_real && board0 + tb < B;
-    const int64_t my_board = tok_valid ? board0 + tb : (B - 1);  // clamped: loads stay in bounds, stores are guarded
+    const int tb = tok / SEQ;                       // board in tile (7 = the 9 pad tokens)
+    const int tc = tok - tb * SEQ;                  // position (0 = CLS)
+    const bool tok_valid = tb < NBOARD && board0 + tb < B;
 
-    // ---- embedding + positional code + CLS: R^T[f][tok]   (MODE_TAIL: the parked CLS residual row)
+    // ---- attention window of this wave: 64 key slots starting at kb cover every board its 32 queries belong to
+    const int kb = w == 0 ? 0 : (w == 1 ? 16 : (w == 2 ? 48 : 64));
+    int k_rd[2], vt_rd[4], k_wr[2], vt_wr[2];
+    for (int ks = 0; ks < 2; ++ks) k_rd[ks] = L_K + kb * 64 + lo.a32[ks];                 // + 32 rows * 64 B per key tile
+    for (int ks = 0; ks < 4; ++ks) vt_rd[ks] = L_VT + r * 256 + (((kb / 8 + 2 * ks + h) ^ swz<16>(r)) * 16);
+    for (int s = 0; s < 2; ++s) {
+        k_wr[s] = L_K + tok * 64 + (((2 * s + h) ^ swz<4>(tok)) * 16);                    // lane = token, regs = d
+        vt_wr[s] = L_VT + r * 256 + (((4 * w + 2 * s + h) ^ swz<16>(r)) * 16);            // lane = d, regs = tokens
+    }
+    // board one-hot codes (x16) for the masking MFMA step: element j of lane half h is reduction index 8h + j
+    bf16x8 kmask[2], qmask;
+    {
+        const int qb = tb;
+        for (int j = 0; j < 8; ++j) qmask[j] = (__bf16)((qb == 8 * h + j) ? 16.0f : 0.0f);
+        for (int tl = 0; tl < 2; ++tl) {
+            const int kbd = (kb + 32 * tl + r) / SEQ;
+            for (int j = 0; j < 8; ++j) kmask[tl][j] = (__bf16)((kbd == 8 * h + j) ? 16.0f : 0.0f);
+        }
+        park_in_agpr(qmask);
+        park_in_agpr(kmask[0]);
+        park_in_agpr(kmask[1]);
+    }
+
+    // ---- embedding + positional code + CLS: R^T[f][tok]
     f32x16 R[8];
-    if (MODE == MODE_TAIL) {
-        const float *src = ws_r + my_board * D;
-        for (int j = 0; j < 8; ++j)
-            for (int i = 0; i < 16; ++i) R[j][i] = src[32 * j + rowof(i, h)];
-    } else {
+    {
         const float *src = cls;
-        if (tok_valid && tc != 0) src = table + ((size_t)(tc - 1) * 31 + boards[(board0 + tb) * 16 + (tc - 1)]) * D;
+        if (tok_valid && tc != 0) {
+            int e = boards[(board0 + tb) * 16 + (tc - 1)];
+            e = e > 30 ? 30 : e;  // the table has 31 rows per cell
+            src = table + ((size_t)(tc - 1) * 31 + e) * D;
+        }
         const float keep = tok_valid ? 1.0f : 0.0f;
         for (int j = 0; j < 8; ++j)
-            for (int i = 0; i < 16; ++i) R[j][i] = keep * src[32 * j + rowof(i, h)];
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 32 * j + 8 * g + 4 * h);
+                for (int q = 0; q < 4; ++q) R[j][4 * g + q] = keep * v[q];
+            }
+    }
+
+    const int full_layers = MODE == MODE_HEAD ? n_layers - 1 : n_layers;
+    char *const lds = L.w;
+    // the weight blob as a buffer resource; tile addresses below are byte offsets into it (< 2^31: 1.5 MB per layer)
+    const rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(wblob), 0, n_layers * (W_LAYER * 2), 0x00020000);
+    auto wqkv = [&](int hd) -> char * { return lds + L_WQKV + (hd & 1) * 3 * TILE; };
+    // lw = byte offset of the layer's weights; tiles first..last-1 of {q, k, v} of head hd
+    auto dma_qkv = [&](unsigned lw, int hd, int first = 0, int last = 3) __attribute__((always_inline)) {
+        for (int t = first; t < last; ++t)
+            dma_tile<32>(wqkv(hd) + t * TILE, blob, lw + 2u * (unsigned)(WO_QKV + (t * D + HD * hd) * D), D, HD, lo, w);
+    };
+    auto dma_wo = [&](unsigned lw, int hd) __attribute__((always_inline)) {
+        dma_tile<4>(lds + L_WO, blob, lw + 2u * (unsigned)(WO_O + HD * hd), D, D, lo, w);
+    };
+    auto dma_w1 = [&](unsigned lw, int c) __attribute__((always_inline)) {
+        dma_tile<32>(lds + L_W1 + (c & 1) * 2 * TILE, blob, lw + 2u * (unsigned)(WO_1 + FFC * c * D), D, FFC, lo, w);
+    };
+    auto dma_w2 = [&](unsigned lw, int c) __attribute__((always_inline)) {
+        dma_tile<8>(lds + L_W2 + (c & 1) * 2 * TILE, blob, lw + 2u * (unsigned)(WO_2 + FFC * c), FF, D, lo, w);
+    };
+
+    if (full_layers > 0) {  // prologue of layer 0: in_proj tiles of heads 0 and 1
+        dma_qkv(0u, 0);
+        dma_qkv(0u, 1);
     }
 
 #pragma nounroll
-    for (int layer = (MODE == MODE_TAIL ? n_layers - 1 : 0); layer < (MODE == MODE_HEAD ? n_layers - 1 : n_layers); ++layer) {
-        const __bf16 *W = wblob + (size_t)layer * W_LAYER;
+    for (int layer = 0; layer < full_layers; ++layer) {
+        const unsigned lw = (unsigned)layer * (unsigned)(W_LAYER * 2);
         const float *P = pblob + (size_t)layer * P_LAYER;
-        auto dma_qkv = [&](int hd) {
-            dma_tile<32>(wq, W + WO_QKV + (size_t)(0 * D + HD * hd) * D, D, HD, lo, w);
-            if (MODE != MODE_TAIL) {
-                dma_tile<32>(wk, W + WO_QKV + (size_t)(1 * D + HD * hd) * D, D, HD, lo, w);
-                dma_tile<32>(wv, W + WO_QKV + (size_t)(2 * D + HD * hd) * D, D, HD, lo, w);
-            }
-        };
-        auto wo_of = [&](int hd) -> char * { return L.w + (3 + (hd & 1)) * TILE; };  // double-buffered
-        auto dma_wo = [&](int hd) { dma_tile<4>(wo_of(hd), W + WO_O + HD * hd, D, D, lo, w); };
+        const bool has_next = layer + 1 < full_layers;
 
         // ================= attention block =================
-        __syncthreads();  // previous layer's feed-forward tiles (incl. the one aliasing `act`) are no longer read
-        dma_qkv(0);
-        dma_wo(0);
-        stage_f32(L.gamma, P + PO_LN1G, D, tid);
-        stage_f32(L.beta, P + PO_LN1B, D, tid);
-        stage_f32(L.bias, P + PO_BQKV, 3 * D, tid);
-        // zero the attention tiles: padded rows/columns are read (and multiplied by 0) but never written
-        for (int i = tid; i < (int)sizeof(LdsAttn) / 16; i += THREADS)
-            reinterpret_cast<uint4 *>(&A)[i] = make_uint4(0, 0, 0, 0);
-        dma_wait_all();
-        __syncthreads();
+        // on entry: in_proj tiles of heads 0 and 1 are in flight (issued by the prologue / the previous layer's tail)
+        stage_f32(L.bq, P + PO_BQKV, D, tid);
+        stage_f32(L.bo, P + PO_BO, D, tid);
+        stage_f32(L.b1, P + PO_B1, FF, tid);
+        stage_f32(L.b2, P + PO_B2, D, tid);
         bf16x8 xn[16];
-        layer_norm(R, L.gamma, L.beta, h, xn);
+        layer_norm(R, xn);
+        dma_wait_all();
+        __syncthreads();  // tiles of heads 0/1 and the biases visible
 
-#pragma nounroll
-        for (int hd = 0; hd < NH; ++hd) {
-            if (MODE == MODE_TAIL) {
-                // Q^T [32 d][32 boards] of the CLS tokens; the single query of a board attends to that board's 17 keys
-                // in-lane: this lane half holds 16 of the 32 head dims (d = rowof(i, h)), exactly the 16 contiguous
-                // values MODE_HEAD parked per (board, head, key, half)
-                const f32x16 zero = {0};
-                f32x16 qa = gemm_tile<32, 16>(wq, lo, 0, xn, zero);
-                pipe_mfma<16>();
-                for (int i = 0; i < 16; ++i) qa[i] += L.bias[0 * D + HD * hd + rowof(i, h)];
-                const size_t off = (size_t)my_board * KV_ELEMS + (size_t)hd * SEQ * HD + 16 * h;
-                float sc[SEQ], m = -3.0e38f;
-                for (int key = 0; key < SEQ; ++key) {
-                    const bf16x8 k0 = *reinterpret_cast<const bf16x8 *>(ws_k + off + key * HD);
-                    const bf16x8 k1 = *reinterpret_cast<const bf16x8 *>(ws_k + off + key * HD + 8);
-                    float d = 0.f;
-                    // q is rounded to bf16 like the operand of the full kernel's K Q^T product
-                    for (int i = 0; i < 8; ++i) d += (float)(__bf16)qa[i] * (float)k0[i] + (float)(__bf16)qa[8 + i] * (float)k1[i];
-                    d += __shfl_xor(d, 32);
-                    sc[key] = d * 0.17677669529663687f;
-                    m = fmaxf(m, sc[key]);
-                }
-                float sum = 0.f;
-                for (int key = 0; key < SEQ; ++key) {
-                    sc[key] = __expf(sc[key] - m);
-                    sum += sc[key];
-                }
-                const float inv = 1.0f / sum;
-                float o[16];
-                for (int i = 0; i < 16; ++i) o[i] = 0.f;
-                for (int key = 0; key < SEQ; ++key) {
-                    const bf16x8 v0 = *reinterpret_cast<const bf16x8 *>(ws_v + off + key * HD);
-                    const bf16x8 v1 = *reinterpret_cast<const bf16x8 *>(ws_v + off + key * HD + 8);
-                    const float p = (float)(__bf16)(sc[key] * inv);  // bf16 probabilities, as the MFMA operand would be
-                    for (int i = 0; i < 8; ++i) {
-                        o[i] += p * (float)v0[i];
-                        o[8 + i] += p * (float)v1[i];
+        // ---- explicit software pipeline.  Step i = MFMA i of the next head's q | k | v projection chains (K = 256: 16 steps
+        // each), the operand read PD steps ahead, and a slice of this head's softmax for the vector ALU; sched_fence() ends
+        // every step, so each MFMA is followed by its few vector instructions instead of the compiler's
+        // all-MFMAs-then-all-VALU order (one wave per SIMD: only instructions of this wave can fill the matrix pipe's shadow).
+        //   Q^T gets its bias through the accumulator; K^T has none (folded away); V is computed with swapped operands,
+        //   tokens on the accumulator's rows, so that V^T can be written to LDS as 16-byte runs.
+        bf16x8 qf[2], kf[2], vf[2];
+        constexpr int PD = 8;
+        auto project = [&](int hd, auto softmax_tag, f32x16 &s0, f32x16 &s1, bf16x8 *pf, float &sum) __attribute__((always_inline)) {
+            constexpr bool SOFTMAX = decltype(softmax_tag)::value;
+            const char *t = wqkv(hd);
+            bf16x8 a[PD];
+            f32x16 qa = bias_tile(L.bq + HD * hd, h), ka = {0}, va = {0};
+            static_for<0, PD>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                a[i] = load_w<32>(t + (i / 16) * TILE, lo, 0, i % 16);
+            });
+            float m = 0.f, mc = 0.f;
+            sched_fence();
+            static_for<0, 48>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int ks = i % 16;
+                if constexpr (i < 16) qa = mfma(a[i % PD], xn[ks], qa);
+                else if constexpr (i < 32) ka = mfma(a[i % PD], xn[ks], ka);
+                else va = mfma(xn[ks], a[i % PD], va);
+                if constexpr (i + PD < 48) a[i % PD] = load_w<32>(t + ((i + PD) / 16) * TILE, lo, 0, (i + PD) % 16);
+                if constexpr (SOFTMAX) {
+                    if constexpr (i < 8) {  // running maximum, 4 scores per step
+                        const float x = fmaxf(fmaxf(s0[2 * i], s0[2 * i + 1]), fmaxf(s1[2 * i], s1[2 * i + 1]));
+                        m = i == 0 ? x : fmaxf(m, x);
+                    } else if constexpr (i == 8) {
+                        m = xhalf_max(m);
+                        mc = -m * SM_SCALE_LOG2E;
+                        sum = 0.f;
+                    } else if constexpr (i < 41) {  // one probability per step: p = exp2((s - max) / sqrt(32) * log2 e)
+                        constexpr int e = i - 9;
+                        if constexpr (e < 16) {
+                            s0[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], SM_SCALE_LOG2E, mc));
+                            sum += s0[e];
+                        } else {
+                            s1[e - 16] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e - 16], SM_SCALE_LOG2E, mc));
+                            sum += s1[e - 16];
+                        }
+                    } else if constexpr (i == 41) {
+                        sum = xhalf_sum(sum);
+                    } else if constexpr (i < 46) {  // bf16 operand fragments of P^T, one k-step (16 keys) per step
+                        constexpr int k = i - 42;
+                        for (int j = 0; j < 8; ++j) {
+                            if constexpr (k < 2) pf[k][j] = (__bf16)s0[8 * (k & 1) + j];
+                            else pf[k][j] = (__bf16)s1[8 * (k & 1) + j];
+                        }
                     }
                 }
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 ov;
-                    for (int q = 0; q < 4; ++q) ov[q] = (__bf16)o[4 * g + q];
-                    *reinterpret_cast<bf16x4 *>(A.o + tok * ST32 + 2 * (8 * g + 4 * h)) = ov;
-                }
-                __syncthreads();  // O visible; this head's Q tile is free
-                if (hd + 1 < NH) {
-                    dma_qkv(hd + 1);
-                    dma_wo(hd + 1);
-                }
-                bf16x8 of[2];
-                for (int ks = 0; ks < 2; ++ks) of[ks] = load_p(A.o + tok * ST32, ks, h);
-                const char *wo = wo_of(hd);
-                for (int j = 0; j < 8; ++j) R[j] = gemm_tile<4, 2>(wo, lo, j, of, R[j]);
-                pipe_mfma<16>();
-                dma_wait_all();
-                __syncthreads();  // next head's tiles landed; O of this head is free
-                continue;
+                if constexpr (i >= 20 && i < 22)  // q chain finished at step 15 (16 passes of latency later its tile is readable)
+                    for (int j = 0; j < 8; ++j) qf[i - 20][j] = (__bf16)qa[8 * (i - 20) + j];
+                if constexpr (i >= 36 && i < 38)
+                    for (int j = 0; j < 8; ++j) kf[i - 36][j] = (__bf16)ka[8 * (i - 36) + j];
+                sched_fence();
+            });
+            frag_from_acc(va, vf);
+        };
+        auto store_kv = [&]() __attribute__((always_inline)) {
+            for (int s = 0; s < 2; ++s) {
+                *reinterpret_cast<bf16x8 *>(lds + k_wr[s]) = kf[s];
+                *reinterpret_cast<bf16x8 *>(lds + vt_wr[s]) = vf[s];
             }
-            // Q^T, K^T, V^T [32 d][32 tok] for this wave's tokens
-            const f32x16 zero = {0};
-            f32x16 qa = gemm_tile<32, 16>(wq, lo, 0, xn, zero);
-            f32x16 ka = gemm_tile<32, 16>(wk, lo, 0, xn, zero);
-            f32x16 va = gemm_tile<32, 16>(wv, lo, 0, xn, zero);
-            pipe_mfma<48>();
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 qv, kv;
-                for (int q = 0; q < 4; ++q) {
-                    const int i = 4 * g + q, d = rowof(i, h);
-                    qv[q] = (__bf16)(qa[i] + L.bias[0 * D + HD * hd + d]);
-                    kv[q] = (__bf16)(ka[i] + L.bias[1 * D + HD * hd + d]);
-                    va[i] += L.bias[2 * D + HD * hd + d];
-                }
-                *reinterpret_cast<bf16x4 *>(A.q + tok * ST32 + 2 * (8 * g + 4 * h)) = qv;
-                *reinterpret_cast<bf16x4 *>(A.k + tok * ST32 + 2 * (8 * g + 4 * h)) = kv;
-            }
-            if (tok_real) {
-                char *vcol = A.vt + 2 * (32 * tb + kperm_pos(tc));
-                for (int i = 0; i < 16; ++i) *reinterpret_cast<__bf16 *>(vcol + rowof(i, h) * STVT) = (__bf16)va[i];
-            }
-            __syncthreads();  // Q/K/V^T visible; in_proj tiles of this head are free
-            if (hd + 1 < NH) {  // next head's weights land while this head's attention and out_proj run
-                dma_qkv(hd + 1);
-                dma_wo(hd + 1);
-            }
-            // attention of board b: S^T[key][query] = K Q^T, softmax over keys (registers), O^T = V^T P^T
-            for (int b = w; b < NBOARD; b += 4) {
-                const int t0 = SEQ * b;
-                f32x16 s = {0};
-                for (int ks = 0; ks < 2; ++ks)
-                    s = mfma(load_p(A.k + (t0 + r) * ST32, ks, h), load_p(A.q + (t0 + r) * ST32, ks, h), s);
-                float m = -3.0e38f;
-                for (int i = 0; i < 16; ++i) {
-                    s[i] = rowof(i, h) < SEQ ? s[i] * 0.17677669529663687f : -3.0e38f;
-                    m = fmaxf(m, s[i]);
-                }
-                m = fmaxf(m, __shfl_xor(m, 32));
-                float sum = 0.f;
-                for (int i = 0; i < 16; ++i) {
-                    s[i] = rowof(i, h) < SEQ ? __expf(s[i] - m) : 0.0f;
-                    sum += s[i];
-                }
-                sum += __shfl_xor(sum, 32);
-                const float inv = 1.0f / sum;
-                for (int i = 0; i < 16; ++i) s[i] *= inv;
-                bf16x8 pfr[2];
-                frag_from_acc(s, pfr);
-                f32x16 o = {0};
-                for (int ks = 0; ks < 2; ++ks) o = mfma(load_p(A.vt + r * STVT + 2 * 32 * b, ks, h), pfr[ks], o);
-                if (r < SEQ)
-                    for (int g = 0; g < 4; ++g) {
-                        bf16x4 ov;
-                        for (int q = 0; q < 4; ++q) ov[q] = (__bf16)o[4 * g + q];
-                        *reinterpret_cast<bf16x4 *>(A.o + (t0 + r) * ST32 + 2 * (8 * g + 4 * h)) = ov;
-                    }
-            }
-            __syncthreads();  // O visible
-            // R^T += Wo[:, head] . O^T
-            bf16x8 of[2];
-            for (int ks = 0; ks < 2; ++ks) of[ks] = load_p(A.o + tok * ST32, ks, h);
-            const char *wo = wo_of(hd);
-            for (int j = 0; j < 8; ++j) R[j] = gemm_tile<4, 2>(wo, lo, j, of, R[j]);
-            pipe_mfma<16>();
-            dma_wait_all();
-            __syncthreads();  // next head's tiles landed; Q/K/V^T/O of this head are free
+        };
+        {
+            f32x16 d0, d1;
+            float dsum;
+            project(0, std::false_type{}, d0, d1, nullptr, dsum);
         }
+        store_kv();
+        __syncthreads();  // K / V^T of head 0 visible; head 0's in_proj tiles are free
+
+        // one head: scores + softmax + P.V for head hd (Q^T in qf, K / V^T in LDS), the next head's projections in the
+        // shadow of the softmax, then out-proj.  NEXT: 0 = head hd+2 exists (its in_proj tiles are fetched), 1 = hd = 6
+        // (linear1 chunk 0 is fetched instead), 2 = hd = 7 (last head: linear1 chunk 1 and linear2 chunk 0 are fetched).
+        auto head = [&](int hd, auto next_tag) __attribute__((always_inline)) {
+            constexpr int NEXT = decltype(next_tag)::value;
+            // this head's K fragments first: their LDS latency hides behind the fetch issue below
+            bf16x8 kr[4];
+            for (int ks = 0; ks < 2; ++ks) {
+                kr[2 * ks] = *reinterpret_cast<const bf16x8 *>(lds + k_rd[ks]);
+                kr[2 * ks + 1] = *reinterpret_cast<const bf16x8 *>(lds + k_rd[ks] + 32 * 64);
+            }
+            sched_fence();
+            // weight stream: this head's out-proj slice first (waited for at barrier 1), then what the next iteration needs
+            dma_wo(lw, hd);
+            if constexpr (NEXT == 0) dma_qkv(lw, hd + 2);
+            if constexpr (NEXT == 1) dma_w1(lw, 0);
+            if constexpr (NEXT == 2) {
+                dma_w1(lw, 1);
+                dma_w2(lw, 0);
+            }
+            sched_fence();
+            // S^T[key][query] = K Q^T for the two 32-key tiles of the window, + 256 on same-board pairs
+            f32x16 s0 = {0}, s1 = {0};
+            for (int ks = 0; ks < 2; ++ks) {
+                s0 = mfma(kr[2 * ks], qf[ks], s0);
+                s1 = mfma(kr[2 * ks + 1], qf[ks], s1);
+            }
+            s0 = mfma(kmask[0], qmask, s0);
+            s1 = mfma(kmask[1], qmask, s1);
+            sched_fence();
+            // softmax over the 64 key slots: in-lane, one exchange with lane^32 each for the maximum and the sum;
+            // probabilities stay unnormalised (<= 1), O is scaled by 1/sum afterwards
+            bf16x8 pf[4];
+            float sum;
+            if constexpr (NEXT != 2) {
+                project(hd + 1, std::true_type{}, s0, s1, pf, sum);
+            } else {
+                float m = fmaxf(s0[0], s1[0]);
+                for (int i = 1; i < 16; ++i) m = fmaxf(m, fmaxf(s0[i], s1[i]));
+                m = xhalf_max(m);
+                const float mc = -m * SM_SCALE_LOG2E;
+                sum = 0.f;
+                for (int i = 0; i < 16; ++i) {
+                    s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], SM_SCALE_LOG2E, mc));
+                    s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], SM_SCALE_LOG2E, mc));
+                    sum += s0[i] + s1[i];
+                }
+                sum = xhalf_sum(sum);
+                frag_from_acc(s0, pf);
+                frag_from_acc(s1, pf + 2);
+            }
+            sched_fence();
+            // O^T[d][query] = V^T P^T over the window
+            f32x16 o = {0};
+            for (int ks = 0; ks < 4; ++ks) o = mfma(*reinterpret_cast<const bf16x8 *>(lds + vt_rd[ks]), pf[ks], o);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+            for (int i = 0; i < 16; ++i) o[i] *= inv;
+            bf16x8 of[2];
+            frag_from_acc(o, of);
+            // barrier 1: every wave is done with this head's K / V^T and the next head's in_proj tiles; the out-proj
+            // slice has landed (only the younger fetches may still be in flight)
+            if constexpr (NEXT == 0) dma_wait<12>();
+            if constexpr (NEXT == 1) dma_wait<8>();
+            if constexpr (NEXT == 2) dma_wait<16>();
+            // raw barrier: __syncthreads() would drain the fetches that are meant to stay in flight (vmcnt(0))
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            sched_fence();
+            if constexpr (NEXT != 2) store_kv();
+            // R^T += Wo[:, head] . O^T: 16 MFMAs, operand reads PD ahead
+            {
+                const char *wo = lds + L_WO;
+                bf16x8 a[PD];
+                static_for<0, PD>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    a[i] = load_w<4>(wo, lo, i / 2, i % 2);
+                });
+                sched_fence();
+                static_for<0, 16>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    R[i / 2] = mfma(a[i % PD], of[i % 2], R[i / 2]);
+                    if constexpr (i + PD < 16) a[i % PD] = load_w<4>(wo, lo, (i + PD) / 2, (i + PD) % 2);
+                    sched_fence();
+                });
+            }
+            // barrier 2: next head's K / V^T visible, everything fetched in this iteration has landed
+            dma_wait_all();
+            __syncthreads();
+        };
+#pragma nounroll
+        for (int hd = 0; hd < NH - 2; ++hd) head(hd, std::integral_constant<int, 0>{});
+        head(NH - 2, std::integral_constant<int, 1>{});
+        head(NH - 1, std::integral_constant<int, 2>{});
 
         // ================= feed-forward block =================
-        auto w1_of = [&](int c) -> char * { return L.w + ((c & 1) ? 2 * TILE : 0); };
-        auto w2_of = [&](int c) -> char * { return (c & 1) ? L.act.w2b : L.w + 4 * TILE; };
-        auto dma_ffn = [&](int c) {
-            dma_tile<32>(w1_of(c), W + WO_1 + (size_t)(FFC * c) * D, D, FFC, lo, w);
-            dma_tile<8>(w2_of(c), W + WO_2 + FFC * c, FF, D, lo, w);
-        };
-        dma_ffn(0);
-        stage_f32(L.bias, P + PO_BO, D, tid);
-        stage_f32(L.gamma, P + PO_LN2G, D, tid);
-        stage_f32(L.beta, P + PO_LN2B, D, tid);
-        __syncthreads();
-        for (int j = 0; j < 8; ++j)
-            for (int i = 0; i < 16; ++i) R[j][i] += L.bias[32 * j + rowof(i, h)];
-        layer_norm(R, L.gamma, L.beta, h, xn);
-        __syncthreads();
-        stage_f32(L.bias, P + PO_B1, FF, tid);
-        dma_wait_all();
-        __syncthreads();
-#pragma nounroll
-        for (int c = 0; c < FF / FFC; ++c) {
-            if (c + 1 < FF / FFC) dma_ffn(c + 1);  // lands while this stage computes
-            const char *t1 = w1_of(c), *t2 = w2_of(c);
-            const f32x16 zero = {0};
-            f32x16 h0 = gemm_tile<32, 16>(t1, lo, 0, xn, zero);
-            f32x16 h1 = gemm_tile<32, 16>(t1, lo, 1, xn, zero);
-            pipe_mfma<32>();
-            for (int i = 0; i < 16; ++i) {
-                h0[i] = fmaxf(h0[i] + L.bias[FFC * c + rowof(i, h)], 0.0f);
-                h1[i] = fmaxf(h1[i] + L.bias[FFC * c + 32 + rowof(i, h)], 0.0f);
-            }
-            bf16x8 hf[4];
-            frag_from_acc(h0, hf);
-            frag_from_acc(h1, hf + 2);
-            for (int j = 0; j < 8; ++j) R[j] = gemm_tile<8, 4>(t2, lo, j, hf, R[j]);
-            pipe_mfma<32>();
-            dma_wait_all();
-            __syncthreads();  // next stage landed; this stage's tiles are free
+        // on entry: linear1 chunks 0 and 1 and linear2 chunk 0 are in LDS (fetched under heads 6 and 7)
+        for (int j = 0; j < 8; ++j) {
+            const f32x16 b = bias_tile(L.bo + 32 * j, h);
+            for (int i = 0; i < 16; ++i) R[j][i] += b[i];
         }
-        for (int j = 0; j < 8; ++j)
-            for (int i = 0; i < 16; ++i) R[j][i] += P[PO_B2 + 32 * j + rowof(i, h)];
+        layer_norm(R, xn);
+        // h(c) = linear1 chunk c (bias through the accumulator), 32 MFMAs, with the packing of the previous chunk's
+        // activations (ReLU, bf16) sliced into its first steps
+        f32x16 h0, h1;
+        bf16x8 hf[4];
+        auto ffn1 = [&](int c, auto pack_tag) __attribute__((always_inline)) {
+            constexpr bool PACK = decltype(pack_tag)::value;
+            const char *t1 = lds + L_W1 + (c & 1) * 2 * TILE;
+            f32x16 n0 = bias_tile(L.b1 + FFC * c, h), n1 = bias_tile(L.b1 + FFC * c + 32, h);
+            bf16x8 a[PD];
+            static_for<0, PD>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                a[i] = load_w<32>(t1, lo, i / 16, i % 16);
+            });
+            sched_fence();
+            static_for<0, 32>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 16) n0 = mfma(a[i % PD], xn[i % 16], n0);
+                else n1 = mfma(a[i % PD], xn[i % 16], n1);
+                if constexpr (i + PD < 32) a[i % PD] = load_w<32>(t1, lo, (i + PD) / 16, (i + PD) % 16);
+                if constexpr (PACK && i < 8) {  // 4 activations of the previous chunk per step: hf[i/2], half i&1
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (i < 4) hf[i / 2][4 * (i & 1) + j] = (__bf16)h0[8 * ((i / 2) & 1) + 4 * (i & 1) + j];
+                        else hf[i / 2][4 * (i & 1) + j] = (__bf16)h1[8 * ((i / 2) & 1) + 4 * (i & 1) + j];
+                    }
+                    if constexpr ((i & 1) != 0) {
+                        s16x2 *p2 = reinterpret_cast<s16x2 *>(&hf[i / 2]);
+                        const s16x2 zero = {0, 0};
+                        for (int q = 0; q < 4; ++q) p2[q] = __builtin_elementwise_max(p2[q], zero);
+                    }
+                }
+                sched_fence();
+            });
+            h0 = n0;
+            h1 = n1;
+        };
+        ffn1(0, std::false_type{});
+        __syncthreads();  // every wave has read linear1 chunk 0: its buffer may be refilled
+        // chunk c: pack relu(h(c)) while h(c+1) = linear1 chunk c+1 runs; then R^T += linear2 chunk c.  LAST = 0: plain,
+        // 1: c = 14 (no linear1 chunk to fetch; next layer's q/k tiles of head 0 instead), 2: c = 15 (no chunk c+1)
+        auto chunk = [&](int c, auto last_tag) __attribute__((always_inline)) {
+            constexpr int LAST = decltype(last_tag)::value;
+            if constexpr (LAST == 0) dma_w1(lw, c + 2);
+            if constexpr (LAST != 2) dma_w2(lw, c + 1);
+            if constexpr (LAST == 1) if (has_next) dma_qkv(lw + W_LAYER * 2, 0, 0, 2);
+            if constexpr (LAST == 2) if (has_next) {
+                dma_qkv(lw + W_LAYER * 2, 0, 2, 3);
+                dma_qkv(lw + W_LAYER * 2, 1);
+            }
+            sched_fence();
+            if constexpr (LAST != 2) {
+                ffn1(c + 1, std::true_type{});
+            } else {
+                relu_frag_from_acc(h0, hf);
+                relu_frag_from_acc(h1, hf + 2);
+            }
+            {
+                const char *t2 = lds + L_W2 + (c & 1) * 2 * TILE;
+                bf16x8 a[PD];
+                static_for<0, PD>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    a[i] = load_w<8>(t2, lo, i / 4, i % 4);
+                });
+                sched_fence();
+                static_for<0, 32>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    R[i / 4] = mfma(a[i % PD], hf[i % 4], R[i / 4]);
+                    if constexpr (i + PD < 32) a[i % PD] = load_w<8>(t2, lo, (i + PD) / 4, (i + PD) % 4);
+                    sched_fence();
+                });
+            }
+            if constexpr (LAST == 2)  // linear2's bias, read before the barrier behind which the next layer restages it
+                for (int j = 0; j < 8; ++j) {
+                    const f32x16 b = bias_tile(L.b2 + 32 * j, h);
+                    for (int i = 0; i < 16; ++i) R[j][i] += b[i];
+                }
+            dma_wait_all();
+            __syncthreads();  // fetched tiles landed; this chunk's tiles are free
+        };
+#pragma nounroll
+        for (int c = 0; c < FF / FFC - 2; ++c) chunk(c, std::integral_constant<int, 0>{});
+        chunk(FF / FFC - 2, std::integral_constant<int, 1>{});
+        chunk(FF / FFC - 1, std::integral_constant<int, 2>{});
     }
-
 
     if (MODE == MODE_HEAD) {
         // ---- last layer, K/V only: LayerNorm, K^T and V^T of every head -> HBM, CLS residual row -> HBM
-        const __bf16 *W = wblob + (size_t)(n_layers - 1) * W_LAYER;
-        const float *P = pblob + (size_t)(n_layers - 1) * P_LAYER;
-        auto dma_kv = [&](int hd) {
-            dma_tile<32>(wk, W + WO_QKV + (size_t)(1 * D + HD * hd) * D, D, HD, lo, w);
-            dma_tile<32>(wv, W + WO_QKV + (size_t)(2 * D + HD * hd) * D, D, HD, lo, w);
-        };
-        __syncthreads();  // previous layer's feed-forward tiles are no longer read
+        const unsigned lwl = (unsigned)(n_layers - 1) * (unsigned)(W_LAYER * 2);
+        auto dma_kv = [&](int hd) __attribute__((always_inline)) { dma_qkv(lwl, hd, 1, 3); };
+        __syncthreads();  // the last feed-forward tiles are no longer read
         dma_kv(0);
-        stage_f32(L.gamma, P + PO_LN1G, D, tid);
-        stage_f32(L.beta, P + PO_LN1B, D, tid);
-        stage_f32(L.bias, P + PO_BQKV, 3 * D, tid);
-        dma_wait_all();
-        __syncthreads();
         if (tok_valid && tc == 0) {
             float *dst = ws_r + (board0 + tb) * D;
             for (int j = 0; j < 8; ++j)
-                for (int i = 0; i < 16; ++i) dst[32 * j + rowof(i, h)] = R[j][i];
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+                    for (int q = 0; q < 4; ++q) v[q] = R[j][4 * g + q];
+                    *reinterpret_cast<f32x4 *>(dst + 32 * j + 8 * g + 4 * h) = v;
+                }
         }
         bf16x8 xn[16];
-        layer_norm(R, L.gamma, L.beta, h, xn);
+        layer_norm(R, xn);
+        dma_wait_all();
+        __syncthreads();
 #pragma nounroll
         for (int hd = 0; hd < NH; ++hd) {
+            if (hd + 1 < NH) dma_kv(hd + 1);  // the other buffer: its last reader finished before the previous barrier
+            const char *t = wqkv(hd);
             const f32x16 zero = {0};
-            f32x16 ka = gemm_tile<32, 16>(wk, lo, 0, xn, zero);
-            f32x16 va = gemm_tile<32, 16>(wv, lo, 0, xn, zero);
+            f32x16 ka = gemm_tile<32, 16>(t + TILE, lo, 0, xn, zero);
+            f32x16 va = gemm_tile<32, 16>(t + 2 * TILE, lo, 0, xn, zero);
             pipe_mfma<32>();
+            sched_fence();
             if (tok_valid) {
                 const size_t off = (size_t)(board0 + tb) * KV_ELEMS + ((size_t)hd * SEQ + tc) * HD + 16 * h;
-                bf16x8 k0, k1, v0, v1;
-                for (int i = 0; i < 8; ++i) {
-                    k0[i] = (__bf16)(ka[i] + L.bias[1 * D + HD * hd + rowof(i, h)]);
-                    k1[i] = (__bf16)(ka[8 + i] + L.bias[1 * D + HD * hd + rowof(8 + i, h)]);
-                    v0[i] = (__bf16)(va[i] + L.bias[2 * D + HD * hd + rowof(i, h)]);
-                    v1[i] = (__bf16)(va[8 + i] + L.bias[2 * D + HD * hd + rowof(8 + i, h)]);
-                }
-                *reinterpret_cast<bf16x8 *>(ws_k + off) = k0;
-                *reinterpret_cast<bf16x8 *>(ws_k + off + 8) = k1;
-                *reinterpret_cast<bf16x8 *>(ws_v + off) = v0;
-                *reinterpret_cast<bf16x8 *>(ws_v + off + 8) = v1;
+                bf16x8 f[2];
+                frag_from_acc(ka, f);
+                *reinterpret_cast<bf16x8 *>(ws_k + off) = f[0];
+                *reinterpret_cast<bf16x8 *>(ws_k + off + 8) = f[1];
+                frag_from_acc(va, f);
+                *reinterpret_cast<bf16x8 *>(ws_v + off) = f[0];
+                *reinterpret_cast<bf16x8 *>(ws_v + off + 8) = f[1];
             }
-            __syncthreads();  // this head's K/V weight tiles are free
-            if (hd + 1 < NH) dma_kv(hd + 1);
             dma_wait_all();
             __syncthreads();
         }
         return;
     }
 
-    // ---- CLS rows out (MODE_TAIL: every lane's token is one)
+    // ---- CLS rows out
     if (tok_valid && tc == 0) {
         float *dst = features + (board0 + tb) * D;
         for (int j = 0; j < 8; ++j)
-            for (int i = 0; i < 16; ++i) dst[32 * j + rowof(i, h)] = R[j][i];
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+                for (int q = 0; q < 4; ++q) v[q] = R[j][4 * g + q];
+                *reinterpret_cast<f32x4 *>(dst + 32 * j + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tail kernel: the CLS token of 128 boards per workgroup (one board per lane) through the rest of the last layer
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ST32 = 2 * 32 + 16;     // padded row of the kernel-written O tile
+struct LdsTail {
+    char w[6 * TILE];                 // wq @0, wo @3 TILE / 4 TILE (alternating heads); feed-forward: w1[c&1] @0 / 2 TILE, w2[0] @4 TILE
+    char w2b[2 * TILE];               // w2[1]
+    char o[NTOK * ST32];
+    float bias[FF];
+};
+static_assert(sizeof(LdsTail) <= 160 * 1024, "LDS budget");
+
+__global__ void __launch_bounds__(THREADS, 1)
+k_encoder_tail(const __bf16 *__restrict__ wblob, const float *__restrict__ pblob, int n_layers, float *__restrict__ features,
+               int64_t B, const __bf16 *__restrict__ ws_k, const __bf16 *__restrict__ ws_v, const float *__restrict__ ws_r) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LdsTail &L = *reinterpret_cast<LdsTail *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t board0 = (int64_t)blockIdx.x * NTOK;
+    char *const wq = L.w;
+    LaneOff lo;
+    lane_offsets(lo, r, h, w, lane);
+    const int tok = 32 * w + r;
+    const bool tok_valid = board0 + tok < B;
+    const int64_t my_board = tok_valid ? board0 + tok : (B - 1);  // clamped: loads stay in bounds, stores are guarded
+
+    f32x16 R[8];
+    {
+        const float *src = ws_r + my_board * D;
+        for (int j = 0; j < 8; ++j)
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 32 * j + 8 * g + 4 * h);
+                for (int q = 0; q < 4; ++q) R[j][4 * g + q] = v[q];
+            }
+    }
+    const rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(wblob), 0, n_layers * (W_LAYER * 2), 0x00020000);
+    const unsigned lw = (unsigned)(n_layers - 1) * (unsigned)(W_LAYER * 2);
+    const float *P = pblob + (size_t)(n_layers - 1) * P_LAYER;
+    auto dma_q = [&](int hd) { dma_tile<32>(wq, blob, lw + 2u * (unsigned)(WO_QKV + HD * hd * D), D, HD, lo, w); };
+    auto wo_of = [&](int hd) -> char * { return L.w + (3 + (hd & 1)) * TILE; };  // double-buffered
+    auto dma_wo = [&](int hd) { dma_tile<4>(wo_of(hd), blob, lw + 2u * (unsigned)(WO_O + HD * hd), D, D, lo, w); };
+
+    // ================= attention block =================
+    dma_q(0);
+    dma_wo(0);
+    stage_f32(L.bias, P + PO_BQKV, D, tid);
+    bf16x8 xn[16];
+    layer_norm(R, xn);
+    dma_wait_all();
+    __syncthreads();
+#pragma nounroll
+    for (int hd = 0; hd < NH; ++hd) {
+        // Q^T [32 d][32 boards] of the CLS tokens; the single query of a board attends to that board's 17 keys
+        // in-lane: this lane half holds 16 of the 32 head dims (d = rowof(i, h)), exactly the 16 contiguous
+        // values the main kernel parked per (board, head, key, half)
+        f32x16 qa = gemm_tile<32, 16>(wq, lo, 0, xn, bias_tile(L.bias + HD * hd, h));
+        pipe_mfma<16>();
+        const size_t off = (size_t)my_board * KV_ELEMS + (size_t)hd * SEQ * HD + 16 * h;
+        float sc[SEQ], m = -3.0e38f;
+        for (int key = 0; key < SEQ; ++key) {
+            const bf16x8 k0 = *reinterpret_cast<const bf16x8 *>(ws_k + off + key * HD);
+            const bf16x8 k1 = *reinterpret_cast<const bf16x8 *>(ws_k + off + key * HD + 8);
+            float d = 0.f;
+            // q is rounded to bf16 like the operand of the main kernel's K Q^T product
+            for (int i = 0; i < 8; ++i) d += (float)(__bf16)qa[i] * (float)k0[i] + (float)(__bf16)qa[8 + i] * (float)k1[i];
+            d = xhalf_sum(d);
+            sc[key] = d * 0.17677669529663687f;
+            m = fmaxf(m, sc[key]);
+        }
+        float sum = 0.f;
+        for (int key = 0; key < SEQ; ++key) {
+            sc[key] = __expf(sc[key] - m);
+            sum += sc[key];
+        }
+        const float inv = 1.0f / sum;
+        float o[16];
+        for (int i = 0; i < 16; ++i) o[i] = 0.f;
+        for (int key = 0; key < SEQ; ++key) {
+            const bf16x8 v0 = *reinterpret_cast<const bf16x8 *>(ws_v + off + key * HD);
+            const bf16x8 v1 = *reinterpret_cast<const bf16x8 *>(ws_v + off + key * HD + 8);
+            const float p = (float)(__bf16)sc[key];  // bf16 probabilities (unnormalised), as the MFMA operand would be
+            for (int i = 0; i < 8; ++i) {
+                o[i] += p * (float)v0[i];
+                o[8 + i] += p * (float)v1[i];
+            }
+        }
+        // O row of this token, head dims in KPERM order (the out-proj slice is packed for accumulator-fed operands):
+        // registers 8s..8s+7 are positions 16s + 8h .. +7
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 ov;
+            for (int q = 0; q < 8; ++q) ov[q] = (__bf16)(o[8 * s + q] * inv);
+            *reinterpret_cast<bf16x8 *>(L.o + tok * ST32 + 2 * (16 * s + 8 * h)) = ov;
+        }
+        __syncthreads();  // O visible; this head's Q tile is free
+        if (hd + 1 < NH) {
+            dma_q(hd + 1);
+            dma_wo(hd + 1);
+        }
+        bf16x8 of[2];
+        for (int ks = 0; ks < 2; ++ks) of[ks] = load_p(L.o + tok * ST32, ks, h);
+        const char *wo = wo_of(hd);
+        for (int j = 0; j < 8; ++j) R[j] = gemm_tile<4, 2>(wo, lo, j, of, R[j]);
+        pipe_mfma<16>();
+        dma_wait_all();
+        __syncthreads();  // next head's tiles landed; O of this head is free
+    }
+
+    // ================= feed-forward block =================
+    auto w1_of = [&](int c) -> char * { return L.w + ((c & 1) ? 2 * TILE : 0); };
+    auto w2_of = [&](int c) -> char * { return (c & 1) ? L.w2b : L.w + 4 * TILE; };
+    auto dma_ffn = [&](int c) {
+        dma_tile<32>(w1_of(c), blob, lw + 2u * (unsigned)(WO_1 + FFC * c * D), D, FFC, lo, w);
+        dma_tile<8>(w2_of(c), blob, lw + 2u * (unsigned)(WO_2 + FFC * c), FF, D, lo, w);
+    };
+    dma_ffn(0);
+    stage_f32(L.bias, P + PO_BO, D, tid);
+    __syncthreads();
+    for (int j = 0; j < 8; ++j) {
+        const f32x16 b = bias_tile(L.bias + 32 * j, h);
+        for (int i = 0; i < 16; ++i) R[j][i] += b[i];
+    }
+    layer_norm(R, xn);
+    __syncthreads();
+    stage_f32(L.bias, P + PO_B1, FF, tid);
+    dma_wait_all();
+    __syncthreads();
+#pragma nounroll
+    for (int c = 0; c < FF / FFC; ++c) {
+        if (c + 1 < FF / FFC) dma_ffn(c + 1);  // lands while this stage computes
+        const char *t1 = w1_of(c), *t2 = w2_of(c);
+        f32x16 h0 = gemm_tile<32, 16>(t1, lo, 0, xn, bias_tile(L.bias + FFC * c, h));
+        f32x16 h1 = gemm_tile<32, 16>(t1, lo, 1, xn, bias_tile(L.bias + FFC * c + 32, h));
+        pipe_mfma<32>();
+        bf16x8 hf[4];
+        relu_frag_from_acc(h0, hf);
+        relu_frag_from_acc(h1, hf + 2);
+        for (int j = 0; j < 8; ++j) R[j] = gemm_tile<8, 4>(t2, lo, j, hf, R[j]);
+        pipe_mfma<32>();
+        dma_wait_all();
+        __syncthreads();  // next stage landed; this stage's tiles are free
+    }
+    if (tok_valid) {
+        float *dst = features + (board0 + tok) * D;
+        for (int j = 0; j < 8; ++j)
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(P + PO_B2 + 32 * j + 8 * g + 4 * h);
+                f32x4 v;
+                for (int q = 0; q < 4; ++q) v[q] = R[j][4 * g + q] + b[q];
+                *reinterpret_cast<f32x4 *>(dst + 32 * j + 8 * g + 4 * h) = v;
+            }
     }
 }
 
@@ -533,39 +857,29 @@ extern "C" int g2048_policy_encoder(const uint8_t *boards, const float *embed_ta
                                     float *features, int64_t B, void *workspace, void *stream) {
     if (!boards || !embed_table || !cls_token || !weights_bf16 || !params_f32 || !features || n_layers < 1 || B <= 0)
         return G2048_EINVAL;
-    if (((uintptr_t)weights_bf16 & 15) || ((uintptr_t)params_f32 & 15) || ((uintptr_t)embed_table & 3) ||
-        ((uintptr_t)workspace & 15))
+    if (((uintptr_t)weights_bf16 & 15) || ((uintptr_t)params_f32 & 15) || ((uintptr_t)embed_table & 15) ||
+        ((uintptr_t)cls_token & 15) || ((uintptr_t)features & 15) || ((uintptr_t)workspace & 15))
         return G2048_EINVAL;
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_encoder<MODE_FULL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_encoder<MODE_HEAD>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_encoder<MODE_TAIL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds));
-        attr_set = true;
-    }
-    static int dbg_set = 0;
-    if (!dbg_set) {
-        dbg_set = 1;
-        if (getenv("G2048_ENCODER_DBG")) {
-            const int v = atoi(getenv("G2048_ENCODER_DBG"));
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &v, sizeof(int));
-        }
-    }
+    // the dynamic-LDS limit is a per-device function attribute: set on every call (no latch, no global state)
+    const void *main_fn = workspace ? reinterpret_cast<const void *>(k_encoder_main<MODE_HEAD>)
+                                    : reinterpret_cast<const void *>(k_encoder_main<MODE_FULL>);
+    if (hipFuncSetAttribute(main_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LdsMain)) != hipSuccess ||
+        (workspace && hipFuncSetAttribute(reinterpret_cast<const void *>(k_encoder_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)sizeof(LdsTail)) != hipSuccess))
+        return -(1000 + (int)hipGetLastError());
     const __bf16 *wb = reinterpret_cast<const __bf16 *>(weights_bf16);
     const unsigned blocks = (unsigned)((B + NBOARD - 1) / NBOARD);
     if (!workspace) {
-        hipLaunchKernelGGL(k_encoder<MODE_FULL>, dim3(blocks), dim3(THREADS), sizeof(Lds), (hipStream_t)stream, boards, embed_table,
-                           cls_token, wb, params_f32, n_layers, features, B, (__bf16 *)nullptr, (__bf16 *)nullptr, (float *)nullptr);
+        hipLaunchKernelGGL(k_encoder_main<MODE_FULL>, dim3(blocks), dim3(THREADS), sizeof(LdsMain), (hipStream_t)stream, boards,
+                           embed_table, cls_token, wb, params_f32, n_layers, features, B, (__bf16 *)nullptr, (__bf16 *)nullptr,
+                           (float *)nullptr);
     } else {
         __bf16 *ws_k = reinterpret_cast<__bf16 *>(workspace), *ws_v = ws_k + B * KV_ELEMS;
         float *ws_r = reinterpret_cast<float *>(ws_v + B * KV_ELEMS);
-        hipLaunchKernelGGL(k_encoder<MODE_HEAD>, dim3(blocks), dim3(THREADS), sizeof(Lds), (hipStream_t)stream, boards, embed_table,
-                           cls_token, wb, params_f32, n_layers, features, B, ws_k, ws_v, ws_r);
-        hipLaunchKernelGGL(k_encoder<MODE_TAIL>, dim3((unsigned)((B + NTOK - 1) / NTOK)), dim3(THREADS), sizeof(Lds), (hipStream_t)stream,
-                           boards, embed_table, cls_token, wb, params_f32, n_layers, features, B, ws_k, ws_v, ws_r);
+        hipLaunchKernelGGL(k_encoder_main<MODE_HEAD>, dim3(blocks), dim3(THREADS), sizeof(LdsMain), (hipStream_t)stream, boards,
+                           embed_table, cls_token, wb, params_f32, n_layers, features, B, ws_k, ws_v, ws_r);
+        hipLaunchKernelGGL(k_encoder_tail, dim3((unsigned)((B + NTOK - 1) / NTOK)), dim3(THREADS), sizeof(LdsTail),
+                           (hipStream_t)stream, wb, params_f32, n_layers, features, B, ws_k, ws_v, ws_r);
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);

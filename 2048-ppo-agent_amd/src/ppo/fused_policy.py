@@ -57,19 +57,32 @@ class FusedPolicy:
         w, p = [], []
         # the kernel feeds accumulator tiles straight back in as MFMA operands; the hardware layout then walks the
         # reduction index of every group of 16 in the order KPERM, so the matrices multiplied against such operands
-        # (in_proj, linear1, linear2) are stored with their input columns in that order
+        # (in_proj, out_proj, linear1, linear2) are stored with their input columns in that order
         kperm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15], device=self.cls.device)
 
         def permuted(m):
             k = m.shape[1]
             idx = (torch.arange(0, k, 16, device=m.device)[:, None] + kperm[None, :]).reshape(-1)
-            return m.detach()[:, idx]
+            return m[:, idx]
 
+        D = 256
+        one, zero = torch.ones(D, device=self.cls.device), torch.zeros(D, device=self.cls.device)
         for l in t.encoder.layers:
-            w += [permuted(l.self_attn.in_proj_weight), l.self_attn.out_proj.weight, permuted(l.linear1.weight),
-                  permuted(l.linear2.weight)]
-            p += [l.norm1.weight, l.norm1.bias, l.self_attn.in_proj_bias, l.self_attn.out_proj.bias, l.norm2.weight,
-                  l.norm2.bias, l.linear1.bias, l.linear2.bias]
+            # parameter folding in f32 (include/g2048.h, g2048_policy_encoder): LayerNorm's affine goes into the Linear
+            # behind it, the key bias is dropped (softmax is invariant to it), the value bias moves into out_proj's
+            f = lambda x: x.detach().float()
+            g1, be1, g2, be2 = f(l.norm1.weight), f(l.norm1.bias), f(l.norm2.weight), f(l.norm2.bias)
+            wqkv, bqkv = f(l.self_attn.in_proj_weight), f(l.self_attn.in_proj_bias)
+            wo, bo = f(l.self_attn.out_proj.weight), f(l.self_attn.out_proj.bias)
+            w1, b1 = f(l.linear1.weight), f(l.linear1.bias)
+            bqkv = bqkv + wqkv @ be1
+            wqkv = wqkv * g1[None, :]
+            bo = bo + wo @ bqkv[2 * D:]
+            bqkv = torch.cat([bqkv[:D], zero, zero])
+            b1 = b1 + w1 @ be2
+            w1 = w1 * g2[None, :]
+            w += [permuted(wqkv), permuted(wo), permuted(w1), permuted(f(l.linear2.weight))]
+            p += [one, zero, bqkv, bo, one, zero, b1, f(l.linear2.bias)]
         self.weights = torch.cat([x.detach().reshape(-1).to(torch.bfloat16) for x in w]).contiguous()
         self.params = torch.cat([x.detach().reshape(-1).float() for x in p]).contiguous()
         # actor / critic heads: bf16 copies made once per refresh (autocast would re-cast all of them at every lock-step)

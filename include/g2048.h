@@ -138,12 +138,18 @@ int g2048_compact(const uint8_t *tr_boards, const uint8_t *tr_meta, const float 
  * 17 tokens, "cls" reduction): boards u8[B][16] -> features f32[B][256], i.e. PPOAgent's
  * `self.transformer(self.input_embedding(obs), reduction="cls")` (src/ppo/ppo_agent.py:103-106,
  * src/ppo/transformer_encoder.py:150-190) in eval mode under bf16 autocast numerics.
- *   embed_table f32[16][31][256] = input_embedding.weight^T[e] + positional code of cell c
- *   cls_token   f32[256]
- *   weights_bf16, per layer: in_proj_weight[768][256] | out_proj.weight[256][256] | linear1.weight[1024][256] |
+ *   embed_table f32[16][31][256] = input_embedding.weight^T[e] + positional code of cell c   (16-byte aligned)
+ *   cls_token   f32[256]                                                                     (16-byte aligned)
+ * The per-layer parameters are passed PACKED (the caller packs once per policy update; src/ppo/fused_policy.py):
+ *   folding, in f32:  LayerNorm's affine goes into the Linear behind it (W' = W diag(gamma), b' = b + W beta, for
+ *     norm1 -> in_proj and norm2 -> linear1); the key bias is dropped (it shifts every score of a query by the same
+ *     amount, softmax does not see it); the value bias moves into out_proj's: bo' = bo + Wo bv' (softmax rows sum to 1);
+ *   column order: the kernel feeds accumulator tiles straight back in as MFMA operands, so the input columns of every
+ *     group of 16 of all four matrices are stored in the order [0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15];
+ *   weights_bf16, per layer: in_proj_weight'[768][256] | out_proj.weight[256][256] | linear1.weight'[1024][256] |
  *                            linear2.weight[256][1024]                                     (bf16, 16-byte aligned)
- *   params_f32,  per layer: norm1.weight[256] | norm1.bias[256] | in_proj_bias[768] | out_proj.bias[256] |
- *                            norm2.weight[256] | norm2.bias[256] | linear1.bias[1024] | linear2.bias[256]
+ *   params_f32,  per layer: ones[256] | zeros[256] | bq'[256], zeros[512] | bo'[256] | ones[256] | zeros[256] |
+ *                            b1'[1024] | linear2.bias[256]   (the slots of the folded LayerNorm affines are unused)
  *
  * workspace: NULL = one kernel carries every token through every layer.  Otherwise
  * g2048_policy_encoder_workspace_bytes(B) bytes (16-byte aligned): the last layer is split - a first kernel parks that

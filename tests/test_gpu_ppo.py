@@ -435,12 +435,13 @@ def test_fused_ppo_loss_matches_torch(dev, dtype, use_mask):
         total.backward()
         got_lp, sums, dl, dv = nv.ppo_loss(logits, values, actions.to(torch.uint8), bits if use_mask else None, old_lp, adv, ret,
                                            0.2, 0.5, 0.01)
-        tol = dict(rtol=2e-4, atol=2e-5)
+        # north_star: losses within 1e-5 of the fp32 path (f32 inputs); bf16 inputs are rounded before either side sees them
+        tol = dict(rtol=1e-5, atol=1e-5)
         assert torch.allclose(got_lp, new_lp.detach(), **tol)
         want = torch.stack([pl.mean(), vl.mean(), el.mean(), total, (old_lp - new_lp).mean()]).detach()
-        assert torch.allclose(sums, want, rtol=2e-4, atol=2e-5), (M, sums, want)
+        assert torch.allclose(sums, want, **tol), (M, sums, want)
         assert dl.dtype == dtype and dv.dtype == dtype and dl.shape == logits.shape
-        gtol = dict(rtol=2e-2, atol=2e-6) if dtype == torch.bfloat16 else dict(rtol=5e-4, atol=1e-8)
+        gtol = dict(rtol=2e-2, atol=2e-6) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-8)
         assert torch.allclose(dl.float(), l32.grad, **gtol), (M, (dl.float() - l32.grad).abs().max())
         assert torch.allclose(dv.float(), v32.grad, **gtol)
         assert torch.equal(sums, nv.ppo_loss(logits, values, actions.to(torch.uint8), bits if use_mask else None, old_lp, adv,
