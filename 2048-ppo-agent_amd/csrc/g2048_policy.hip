@@ -193,6 +193,39 @@ __device__ __forceinline__ void static_for(F &&f) {
 // nothing is scheduled across this point
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
+// Diagnostic build only (-DG2048_STAMPS, tools/stamps_encoder.py; never compiled into the product library): cycle stamps
+// at phase boundaries, summed per phase in scalar registers and written to a table of their own at kernel exit.
+#ifdef G2048_STAMPS
+constexpr int N_STAMPS = 24;
+__device__ unsigned long long g_stamps[N_STAMPS];
+struct Stamps {
+    unsigned long long last, acc[N_STAMPS];
+    __device__ __forceinline__ void start() {
+        for (int i = 0; i < N_STAMPS; ++i) acc[i] = 0;
+        last = now();
+    }
+    __device__ __forceinline__ static unsigned long long now() {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    }
+    __device__ __forceinline__ void mark(int k) {
+        const unsigned long long t = now();
+        acc[k] += t - last;
+        last = t;
+    }
+    __device__ __forceinline__ void flush(int lane, int w) {
+        if (lane == 0 && w == 0 && blockIdx.x % 64 == 0)
+            for (int i = 0; i < N_STAMPS; ++i) atomicAdd(&g_stamps[i], acc[i]);
+    }
+};
+#define STAMP(k) stamps.mark(k)
+#else
+#define STAMP(k)
+#endif
+
 // LDS-DMA of a [rows][CPR*8] bf16 tile (global row stride ld elements) into a swizzled LDS image.  Asynchronous:
 // complete for this wave after s_waitcnt vmcnt(..), for the other waves after the following barrier.
 // `buffer_load_dwordx4 ... offen lds`: the weight blob is one buffer resource (SGPRs), the tile base + per-instruction
@@ -208,6 +241,14 @@ __device__ __forceinline__ void dma_tile(char *dst, rsrc_t blob, unsigned src_by
         __builtin_amdgcn_raw_ptr_buffer_load_lds(blob, (__attribute__((address_space(3))) void *)(dst + (t * 4 + w) * 1024), 16,
                                                  (int)lane_off, (int)(src_byte + (unsigned)(t * rows_per_inst * ld * 2)), 0, 0);
     }
+}
+// one wave-instruction (piece t) of dma_tile
+template <int CPR>
+__device__ __forceinline__ void dma_inst(char *dst, rsrc_t blob, unsigned src_byte, int ld, int t, const LaneOff &o, int w) {
+    const int rows_per_inst = 4 * 64 / CPR;
+    const unsigned lane_off = CPR == 32 ? o.s256[t & 1] : (CPR == 8 ? o.s64 : o.s32);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(blob, (__attribute__((address_space(3))) void *)(dst + (t * 4 + w) * 1024), 16,
+                                             (int)lane_off, (int)(src_byte + (unsigned)(t * rows_per_inst * ld * 2)), 0, 0);
 }
 // all but the N youngest vector-memory operations of this wave have completed (they retire in issue order)
 template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -336,59 +377,72 @@ k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ tab
 
     const int full_layers = MODE == MODE_HEAD ? n_layers - 1 : n_layers;
     char *const lds = L.w;
-    // the weight blob as a buffer resource; tile addresses below are byte offsets into it (< 2^31: 1.5 MB per layer)
+    // The weight blob as a buffer resource; tile addresses below are byte offsets into it (< 2^31: 1.5 MB per layer).
+    // Fetches past its end (the "next layer" prefetch of the last layer) are dropped by the hardware's range check.
     const rsrc_t blob = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(wblob), 0, n_layers * (W_LAYER * 2), 0x00020000);
     auto wqkv = [&](int hd) -> char * { return lds + L_WQKV + (hd & 1) * 3 * TILE; };
-    // lw = byte offset of the layer's weights; tiles first..last-1 of {q, k, v} of head hd
-    auto dma_qkv = [&](unsigned lw, int hd, int first = 0, int last = 3) __attribute__((always_inline)) {
-        for (int t = first; t < last; ++t)
-            dma_tile<32>(wqkv(hd) + t * TILE, blob, lw + 2u * (unsigned)(WO_QKV + (t * D + HD * hd) * D), D, HD, lo, w);
+    // Weight stream, one wave-instruction (1 KiB per wave, 4 KiB per workgroup) at a time so that the fetches can be dealt
+    // out between MFMA steps: 64 of them per head / feed-forward chunk keep the CU's vector-memory path busy for ~1200
+    // cycles, which issued back to back stalls all four waves (lw = byte offset of the layer's weights).
+    auto dma_qkv1 = [&](unsigned lw, int hd, int n) __attribute__((always_inline)) {  // n = 0..11: tile n/4 of {q, k, v}, piece n%4
+        dma_inst<32>(wqkv(hd) + (n / 4) * TILE, blob, lw + 2u * (unsigned)(WO_QKV + ((n / 4) * D + HD * hd) * D), D, n % 4, lo, w);
     };
-    auto dma_wo = [&](unsigned lw, int hd) __attribute__((always_inline)) {
-        dma_tile<4>(lds + L_WO, blob, lw + 2u * (unsigned)(WO_O + HD * hd), D, D, lo, w);
+    auto dma_wo1 = [&](unsigned lw, int hd, int n) __attribute__((always_inline)) {   // n = 0..3
+        dma_inst<4>(lds + L_WO, blob, lw + 2u * (unsigned)(WO_O + HD * hd), D, n, lo, w);
     };
-    auto dma_w1 = [&](unsigned lw, int c) __attribute__((always_inline)) {
-        dma_tile<32>(lds + L_W1 + (c & 1) * 2 * TILE, blob, lw + 2u * (unsigned)(WO_1 + FFC * c * D), D, FFC, lo, w);
+    auto dma_w11 = [&](unsigned lw, int c, int n) __attribute__((always_inline)) {    // n = 0..7
+        dma_inst<32>(lds + L_W1 + (c & 1) * 2 * TILE, blob, lw + 2u * (unsigned)(WO_1 + FFC * c * D), D, n, lo, w);
     };
-    auto dma_w2 = [&](unsigned lw, int c) __attribute__((always_inline)) {
-        dma_tile<8>(lds + L_W2 + (c & 1) * 2 * TILE, blob, lw + 2u * (unsigned)(WO_2 + FFC * c), FF, D, lo, w);
+    auto dma_w21 = [&](unsigned lw, int c, int n) __attribute__((always_inline)) {    // n = 0..7
+        dma_inst<8>(lds + L_W2 + (c & 1) * 2 * TILE, blob, lw + 2u * (unsigned)(WO_2 + FFC * c), FF, n, lo, w);
     };
 
-    if (full_layers > 0) {  // prologue of layer 0: in_proj tiles of heads 0 and 1
-        dma_qkv(0u, 0);
-        dma_qkv(0u, 1);
-    }
+#ifdef G2048_STAMPS
+    Stamps stamps;
+    stamps.start();
+#endif
+    // prologue: in_proj tiles of heads 0 and 1 of layer 0 (HEAD mode with a single layer: its K/V part reads them)
+    for (int n = 0; n < 12; ++n) dma_qkv1(0u, 0, n);
+    for (int n = 0; n < 12; ++n) dma_qkv1(0u, 1, n);
 
+    constexpr int PD = 8;  // operand reads in flight ahead of every MFMA chain
+    bf16x8 xn[16];
 #pragma nounroll
     for (int layer = 0; layer < full_layers; ++layer) {
         const unsigned lw = (unsigned)layer * (unsigned)(W_LAYER * 2);
         const float *P = pblob + (size_t)layer * P_LAYER;
-        const bool has_next = layer + 1 < full_layers;
 
         // ================= attention block =================
         // on entry: in_proj tiles of heads 0 and 1 are in flight (issued by the prologue / the previous layer's tail)
-        stage_f32(L.bq, P + PO_BQKV, D, tid);
-        stage_f32(L.bo, P + PO_BO, D, tid);
-        stage_f32(L.b1, P + PO_B1, FF, tid);
-        stage_f32(L.b2, P + PO_B2, D, tid);
-        bf16x8 xn[16];
+        // the layer's biases: loaded first, written to LDS after the LayerNorm (their latency hides behind it)
+        float stg[7];
+        stg[0] = P[PO_BQKV + tid];
+        stg[1] = P[PO_BO + tid];
+        stg[2] = P[PO_B2 + tid];
+        for (int q = 0; q < 4; ++q) stg[3 + q] = P[PO_B1 + 256 * q + tid];
         layer_norm(R, xn);
+        L.bq[tid] = stg[0];
+        L.bo[tid] = stg[1];
+        L.b2[tid] = stg[2];
+        for (int q = 0; q < 4; ++q) L.b1[256 * q + tid] = stg[3 + q];
         dma_wait_all();
         __syncthreads();  // tiles of heads 0/1 and the biases visible
+        STAMP(0);
 
-        // ---- explicit software pipeline.  Step i = MFMA i of the next head's q | k | v projection chains (K = 256: 16 steps
-        // each), the operand read PD steps ahead, and a slice of this head's softmax for the vector ALU; sched_fence() ends
-        // every step, so each MFMA is followed by its few vector instructions instead of the compiler's
-        // all-MFMAs-then-all-VALU order (one wave per SIMD: only instructions of this wave can fill the matrix pipe's shadow).
-        //   Q^T gets its bias through the accumulator; K^T has none (folded away); V is computed with swapped operands,
-        //   tokens on the accumulator's rows, so that V^T can be written to LDS as 16-byte runs.
+        // ---- explicit software pipeline.  Step i = MFMA i of a head's q | k | v projection chains (K = 256: 16 steps each),
+        // the operand read PD steps ahead, every third step one weight fetch, and a slice of the previous head's softmax for
+        // the vector ALU; sched_fence() ends every step, so each MFMA is followed by its few vector instructions instead
+        // of the compiler's all-MFMAs-then-all-VALU order (one wave per SIMD: only this wave's own instructions can fill
+        // the matrix pipe's shadow).  Q^T gets its bias through the accumulator; K^T has none (folded away); V is
+        // computed with swapped operands, tokens on the accumulator's rows, so that V^T is written as 16-byte runs.
+        f32x16 qa, ka, va;          // projections of the NEXT head (accumulators, packed during the out-proj steps)
         bf16x8 qf[2], kf[2], vf[2];
-        constexpr int PD = 8;
-        auto project = [&](int hd, auto softmax_tag, f32x16 &s0, f32x16 &s1, bf16x8 *pf, float &sum) __attribute__((always_inline)) {
+        auto project = [&](int hd, auto softmax_tag, auto fetch, f32x16 &s0, f32x16 &s1, bf16x8 *pf, float &sum) __attribute__((always_inline)) {
             constexpr bool SOFTMAX = decltype(softmax_tag)::value;
             const char *t = wqkv(hd);
             bf16x8 a[PD];
-            f32x16 qa = bias_tile(L.bq + HD * hd, h), ka = {0}, va = {0};
+            qa = bias_tile(L.bq + HD * hd, h);
+            for (int i = 0; i < 16; ++i) ka[i] = va[i] = 0.f;
             static_for<0, PD>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 a[i] = load_w<32>(t + (i / 16) * TILE, lo, 0, i % 16);
@@ -402,6 +456,7 @@ k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ tab
                 else if constexpr (i < 32) ka = mfma(a[i % PD], xn[ks], ka);
                 else va = mfma(xn[ks], a[i % PD], va);
                 if constexpr (i + PD < 48) a[i % PD] = load_w<32>(t + ((i + PD) / 16) * TILE, lo, 0, (i + PD) % 16);
+                if constexpr (i % 3 == 0) fetch(std::integral_constant<int, i / 3>{});
                 if constexpr (SOFTMAX) {
                     if constexpr (i < 8) {  // running maximum, 4 scores per step
                         const float x = fmaxf(fmaxf(s0[2 * i], s0[2 * i + 1]), fmaxf(s1[2 * i], s1[2 * i + 1]));
@@ -429,13 +484,17 @@ k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ tab
                         }
                     }
                 }
-                if constexpr (i >= 20 && i < 22)  // q chain finished at step 15 (16 passes of latency later its tile is readable)
-                    for (int j = 0; j < 8; ++j) qf[i - 20][j] = (__bf16)qa[8 * (i - 20) + j];
-                if constexpr (i >= 36 && i < 38)
-                    for (int j = 0; j < 8; ++j) kf[i - 36][j] = (__bf16)ka[8 * (i - 36) + j];
                 sched_fence();
             });
-            frag_from_acc(va, vf);
+        };
+        // pack piece n = 0..11 of the projections: half a k-step (4 values) of q | k | v per piece
+        auto pack_qkv = [&](auto nc) __attribute__((always_inline)) {
+            constexpr int n = decltype(nc)::value, which = n / 4, s = (n / 2) & 1, half = n & 1;
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (which == 0) qf[s][4 * half + j] = (__bf16)qa[8 * s + 4 * half + j];
+                else if constexpr (which == 1) kf[s][4 * half + j] = (__bf16)ka[8 * s + 4 * half + j];
+                else vf[s][4 * half + j] = (__bf16)va[8 * s + 4 * half + j];
+            }
         };
         auto store_kv = [&]() __attribute__((always_inline)) {
             for (int s = 0; s < 2; ++s) {
@@ -446,32 +505,35 @@ k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ tab
         {
             f32x16 d0, d1;
             float dsum;
-            project(0, std::false_type{}, d0, d1, nullptr, dsum);
+            project(0, std::false_type{}, [](auto) {}, d0, d1, nullptr, dsum);
+            static_for<0, 12>(pack_qkv);
         }
         store_kv();
         __syncthreads();  // K / V^T of head 0 visible; head 0's in_proj tiles are free
+        STAMP(1);
 
         // one head: scores + softmax + P.V for head hd (Q^T in qf, K / V^T in LDS), the next head's projections in the
-        // shadow of the softmax, then out-proj.  NEXT: 0 = head hd+2 exists (its in_proj tiles are fetched), 1 = hd = 6
-        // (linear1 chunk 0 is fetched instead), 2 = hd = 7 (last head: linear1 chunk 1 and linear2 chunk 0 are fetched).
+        // shadow of the softmax, then out-proj with the packing of those projections in ITS shadow.  Fetched meanwhile:
+        // this head's out-proj slice (waited for at barrier 1) and, NEXT = 0: the in_proj tiles of head hd+2; 1 (hd = 6):
+        // linear1 chunk 0; 2 (hd = 7, the last head): nothing more, the feed-forward prologue fetches the rest.
         auto head = [&](int hd, auto next_tag) __attribute__((always_inline)) {
             constexpr int NEXT = decltype(next_tag)::value;
-            // this head's K fragments first: their LDS latency hides behind the fetch issue below
+            // this head's K fragments first: their LDS latency hides behind the first fetches
             bf16x8 kr[4];
             for (int ks = 0; ks < 2; ++ks) {
                 kr[2 * ks] = *reinterpret_cast<const bf16x8 *>(lds + k_rd[ks]);
                 kr[2 * ks + 1] = *reinterpret_cast<const bf16x8 *>(lds + k_rd[ks] + 32 * 64);
             }
             sched_fence();
-            // weight stream: this head's out-proj slice first (waited for at barrier 1), then what the next iteration needs
-            dma_wo(lw, hd);
-            if constexpr (NEXT == 0) dma_qkv(lw, hd + 2);
-            if constexpr (NEXT == 1) dma_w1(lw, 0);
-            if constexpr (NEXT == 2) {
-                dma_w1(lw, 1);
-                dma_w2(lw, 0);
-            }
+            auto fetch = [&](auto nc) __attribute__((always_inline)) {  // n = 0..15: this iteration's 16 fetches in issue order
+                constexpr int n = decltype(nc)::value;
+                if constexpr (n < 4) dma_wo1(lw, hd, n);
+                else if constexpr (NEXT == 0) dma_qkv1(lw, hd + 2, n - 4);
+                else if constexpr (NEXT == 1 && n < 12) dma_w11(lw, 0, n - 4);
+            };
+            if constexpr (NEXT == 2) static_for<0, 4>(fetch);
             sched_fence();
+            STAMP(2);
             // S^T[key][query] = K Q^T for the two 32-key tiles of the window, + 256 on same-board pairs
             f32x16 s0 = {0}, s1 = {0};
             for (int ks = 0; ks < 2; ++ks) {
@@ -481,12 +543,13 @@ k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ tab
             s0 = mfma(kmask[0], qmask, s0);
             s1 = mfma(kmask[1], qmask, s1);
             sched_fence();
+            STAMP(3);
             // softmax over the 64 key slots: in-lane, one exchange with lane^32 each for the maximum and the sum;
             // probabilities stay unnormalised (<= 1), O is scaled by 1/sum afterwards
             bf16x8 pf[4];
             float sum;
             if constexpr (NEXT != 2) {
-                project(hd + 1, std::true_type{}, s0, s1, pf, sum);
+                project(hd + 1, std::true_type{}, fetch, s0, s1, pf, sum);
             } else {
                 float m = fmaxf(s0[0], s1[0]);
                 for (int i = 1; i < 16; ++i) m = fmaxf(m, fmaxf(s0[i], s1[i]));
@@ -503,6 +566,7 @@ k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ tab
                 frag_from_acc(s1, pf + 2);
             }
             sched_fence();
+            STAMP(4);
             // O^T[d][query] = V^T P^T over the window
             f32x16 o = {0};
             for (int ks = 0; ks < 4; ++ks) o = mfma(*reinterpret_cast<const bf16x8 *>(lds + vt_rd[ks]), pf[ks], o);
@@ -510,17 +574,18 @@ k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ tab
             for (int i = 0; i < 16; ++i) o[i] *= inv;
             bf16x8 of[2];
             frag_from_acc(o, of);
+            STAMP(5);
             // barrier 1: every wave is done with this head's K / V^T and the next head's in_proj tiles; the out-proj
             // slice has landed (only the younger fetches may still be in flight)
             if constexpr (NEXT == 0) dma_wait<12>();
             if constexpr (NEXT == 1) dma_wait<8>();
-            if constexpr (NEXT == 2) dma_wait<16>();
+            if constexpr (NEXT == 2) dma_wait<0>();
             // raw barrier: __syncthreads() would drain the fetches that are meant to stay in flight (vmcnt(0))
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             sched_fence();
-            if constexpr (NEXT != 2) store_kv();
-            // R^T += Wo[:, head] . O^T: 16 MFMAs, operand reads PD ahead
+            STAMP(6);
+            // R^T += Wo[:, head] . O^T: 16 MFMAs, operand reads PD ahead, the next head's q / k / v packed in their shadow
             {
                 const char *wo = lds + L_WO;
                 bf16x8 a[PD];
@@ -533,12 +598,17 @@ k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ tab
                     constexpr int i = decltype(ic)::value;
                     R[i / 2] = mfma(a[i % PD], of[i % 2], R[i / 2]);
                     if constexpr (i + PD < 16) a[i % PD] = load_w<4>(wo, lo, (i + PD) / 2, (i + PD) % 2);
+                    if constexpr (NEXT != 2 && i < 12) pack_qkv(ic);
+                    if constexpr (NEXT != 2 && i == 12) store_kv();
                     sched_fence();
                 });
             }
             // barrier 2: next head's K / V^T visible, everything fetched in this iteration has landed
+            STAMP(7);
             dma_wait_all();
+            STAMP(8);
             __syncthreads();
+            STAMP(9);
         };
 #pragma nounroll
         for (int hd = 0; hd < NH - 2; ++hd) head(hd, std::integral_constant<int, 0>{});
@@ -546,102 +616,122 @@ k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ tab
         head(NH - 1, std::integral_constant<int, 2>{});
 
         // ================= feed-forward block =================
-        // on entry: linear1 chunks 0 and 1 and linear2 chunk 0 are in LDS (fetched under heads 6 and 7)
+        // on entry: linear1 chunk 0 is in LDS (fetched under head 6); chunk 1 and linear2 chunk 0 are fetched here, dealt
+        // out over the bias add and the first linear1 chain
         for (int j = 0; j < 8; ++j) {
+            dma_w11(lw, 1, j);
             const f32x16 b = bias_tile(L.bo + 32 * j, h);
             for (int i = 0; i < 16; ++i) R[j][i] += b[i];
         }
         layer_norm(R, xn);
-        // h(c) = linear1 chunk c (bias through the accumulator), 32 MFMAs, with the packing of the previous chunk's
-        // activations (ReLU, bf16) sliced into its first steps
-        f32x16 h0, h1;
+        STAMP(10);
+        // One feed-forward chunk = one 64-step chain: h(c+1) = linear1 chunk c+1 (32 steps, bias through the accumulator)
+        // with the packing of chunk c's activations (ReLU, bf16) sliced into its first 16 steps, then R^T += linear2 chunk
+        // c (32 steps); the operand reads run PD ahead across the seam, every fourth step issues one weight fetch.
+        // Accumulators ping-pong between (hA0, hA1) and (hB0, hB1) so that packing never waits for a register.
+        f32x16 hA0, hA1, hB0, hB1;
         bf16x8 hf[4];
-        auto ffn1 = [&](int c, auto pack_tag) __attribute__((always_inline)) {
-            constexpr bool PACK = decltype(pack_tag)::value;
-            const char *t1 = lds + L_W1 + (c & 1) * 2 * TILE;
-            f32x16 n0 = bias_tile(L.b1 + FFC * c, h), n1 = bias_tile(L.b1 + FFC * c + 32, h);
-            bf16x8 a[PD];
-            static_for<0, PD>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value;
-                a[i] = load_w<32>(t1, lo, i / 16, i % 16);
-            });
-            sched_fence();
-            static_for<0, 32>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value;
-                if constexpr (i < 16) n0 = mfma(a[i % PD], xn[i % 16], n0);
-                else n1 = mfma(a[i % PD], xn[i % 16], n1);
-                if constexpr (i + PD < 32) a[i % PD] = load_w<32>(t1, lo, (i + PD) / 16, (i + PD) % 16);
-                if constexpr (PACK && i < 8) {  // 4 activations of the previous chunk per step: hf[i/2], half i&1
-                    for (int j = 0; j < 4; ++j) {
-                        if constexpr (i < 4) hf[i / 2][4 * (i & 1) + j] = (__bf16)h0[8 * ((i / 2) & 1) + 4 * (i & 1) + j];
-                        else hf[i / 2][4 * (i & 1) + j] = (__bf16)h1[8 * ((i / 2) & 1) + 4 * (i & 1) + j];
-                    }
-                    if constexpr ((i & 1) != 0) {
-                        s16x2 *p2 = reinterpret_cast<s16x2 *>(&hf[i / 2]);
-                        const s16x2 zero = {0, 0};
-                        for (int q = 0; q < 4; ++q) p2[q] = __builtin_elementwise_max(p2[q], zero);
-                    }
-                }
-                sched_fence();
-            });
-            h0 = n0;
-            h1 = n1;
+        auto pack_h = [&](auto nc, const f32x16 &g0, const f32x16 &g1) __attribute__((always_inline)) {  // piece n = 0..15: 2 values
+            constexpr int n = decltype(nc)::value, k = n / 4, q = n % 4;
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (k < 2) hf[k][2 * q + j] = (__bf16)g0[8 * (k & 1) + 2 * q + j];
+                else hf[k][2 * q + j] = (__bf16)g1[8 * (k & 1) + 2 * q + j];
+            }
+            if constexpr (q == 3) {  // ReLU on the packed pairs as 16-bit integers
+                s16x2 *p2 = reinterpret_cast<s16x2 *>(&hf[k]);
+                const s16x2 zero = {0, 0};
+                for (int u = 0; u < 4; ++u) p2[u] = __builtin_elementwise_max(p2[u], zero);
+            }
         };
-        ffn1(0, std::false_type{});
-        __syncthreads();  // every wave has read linear1 chunk 0: its buffer may be refilled
-        // chunk c: pack relu(h(c)) while h(c+1) = linear1 chunk c+1 runs; then R^T += linear2 chunk c.  LAST = 0: plain,
-        // 1: c = 14 (no linear1 chunk to fetch; next layer's q/k tiles of head 0 instead), 2: c = 15 (no chunk c+1)
-        auto chunk = [&](int c, auto last_tag) __attribute__((always_inline)) {
-            constexpr int LAST = decltype(last_tag)::value;
-            if constexpr (LAST == 0) dma_w1(lw, c + 2);
-            if constexpr (LAST != 2) dma_w2(lw, c + 1);
-            if constexpr (LAST == 1) if (has_next) dma_qkv(lw + W_LAYER * 2, 0, 0, 2);
-            if constexpr (LAST == 2) if (has_next) {
-                dma_qkv(lw + W_LAYER * 2, 0, 2, 3);
-                dma_qkv(lw + W_LAYER * 2, 1);
+        // WITH1: run linear1 of chunk c1 into (n0, n1); WITH2: pack (g0, g1) = h(c2) and run linear2 of chunk c2
+        auto ffn_chain = [&](auto with1_tag, auto with2_tag, int c1, int c2, f32x16 &n0, f32x16 &n1, const f32x16 &g0, const f32x16 &g1,
+                             auto fetch) __attribute__((always_inline)) {
+            constexpr bool WITH1 = decltype(with1_tag)::value, WITH2 = decltype(with2_tag)::value;
+            constexpr int N1 = WITH1 ? 32 : 0, NS = N1 + (WITH2 ? 32 : 0);
+            const char *t1 = lds + L_W1 + (c1 & 1) * 2 * TILE, *t2 = lds + L_W2 + (c2 & 1) * 2 * TILE;
+            if constexpr (WITH1) {
+                n0 = bias_tile(L.b1 + FFC * c1, h);
+                n1 = bias_tile(L.b1 + FFC * c1 + 32, h);
             }
+            bf16x8 a[PD];
+            auto rd = [&](auto sc) __attribute__((always_inline)) {  // operand of step s
+                constexpr int s = decltype(sc)::value;
+                if constexpr (s < N1) a[s % PD] = load_w<32>(t1, lo, s / 16, s % 16);
+                else a[s % PD] = load_w<8>(t2, lo, (s - N1) / 4, (s - N1) % 4);
+            };
+            static_for<0, PD>(rd);
+            if constexpr (!WITH1 && WITH2) static_for<0, 16>([&](auto nc) __attribute__((always_inline)) { pack_h(nc, g0, g1); });
             sched_fence();
-            if constexpr (LAST != 2) {
-                ffn1(c + 1, std::true_type{});
-            } else {
-                relu_frag_from_acc(h0, hf);
-                relu_frag_from_acc(h1, hf + 2);
-            }
-            {
-                const char *t2 = lds + L_W2 + (c & 1) * 2 * TILE;
-                bf16x8 a[PD];
-                static_for<0, PD>([&](auto ic) __attribute__((always_inline)) {
-                    constexpr int i = decltype(ic)::value;
-                    a[i] = load_w<8>(t2, lo, i / 4, i % 4);
-                });
+            static_for<0, NS>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < N1) {
+                    if constexpr (i < 16) n0 = mfma(a[i % PD], xn[i % 16], n0);
+                    else n1 = mfma(a[i % PD], xn[i % 16], n1);
+                } else {
+                    R[(i - N1) / 4] = mfma(a[i % PD], hf[(i - N1) % 4], R[(i - N1) / 4]);
+                }
+                if constexpr (i + PD < NS) rd(std::integral_constant<int, i + PD>{});
+                // 16 fetches per chain, early enough to have landed at its end: every third step of 64, every second of 32
+                if constexpr (NS == 64 ? (i % 3 == 0 && i < 48) : i % 2 == 0) fetch(std::integral_constant<int, NS == 64 ? i / 3 : i / 2>{});
+                if constexpr (WITH1 && WITH2 && i < 16) pack_h(ic, g0, g1);
                 sched_fence();
-                static_for<0, 32>([&](auto ic) __attribute__((always_inline)) {
-                    constexpr int i = decltype(ic)::value;
-                    R[i / 4] = mfma(a[i % PD], hf[i % 4], R[i / 4]);
-                    if constexpr (i + PD < 32) a[i % PD] = load_w<8>(t2, lo, (i + PD) / 4, (i + PD) % 4);
-                    sched_fence();
-                });
-            }
+            });
+        };
+        {   // h(0): linear1 chunk 0 alone, with the 8 fetches of linear2 chunk 0
+            f32x16 dummy0, dummy1;
+            ffn_chain(std::true_type{}, std::false_type{}, 0, 0, hA0, hA1, dummy0, dummy1, [&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value;
+                if constexpr (n < 8) dma_w21(lw, 0, n);
+            });
+        }
+        dma_wait_all();
+        __syncthreads();  // linear1 chunk 1 / linear2 chunk 0 landed; every wave has read linear1 chunk 0
+        STAMP(11);
+        // chunk c: LAST = 0: plain (fetches linear1 chunk c+2 and linear2 chunk c+1); 1: c = 14 (linear2 chunk 15 and the
+        // next layer's q / k tiles of head 0); 2: c = 15 (no linear1; the next layer's v tile of head 0 and head 1's tiles)
+        auto chunk = [&](int c, auto last_tag, f32x16 &n0, f32x16 &n1, const f32x16 &g0, const f32x16 &g1) __attribute__((always_inline)) {
+            constexpr int LAST = decltype(last_tag)::value;
+            auto fetch = [&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value;
+                if constexpr (LAST == 0) {
+                    if constexpr (n < 8) dma_w11(lw, c + 2, n);
+                    else dma_w21(lw, c + 1, n - 8);
+                } else if constexpr (LAST == 1) {
+                    if constexpr (n < 8) dma_w21(lw, c + 1, n);
+                    else dma_qkv1(lw + W_LAYER * 2, 0, n - 8);        // q, k tiles of head 0
+                } else {
+                    if constexpr (n < 4) dma_qkv1(lw + W_LAYER * 2, 0, 8 + n);  // v tile of head 0
+                    else dma_qkv1(lw + W_LAYER * 2, 1, n - 4);
+                }
+            };
+            STAMP(12);
+            if constexpr (LAST != 2) ffn_chain(std::true_type{}, std::true_type{}, c + 1, c, n0, n1, g0, g1, fetch);
+            else ffn_chain(std::false_type{}, std::true_type{}, 0, c, n0, n1, g0, g1, fetch);
+            STAMP(14);
             if constexpr (LAST == 2)  // linear2's bias, read before the barrier behind which the next layer restages it
                 for (int j = 0; j < 8; ++j) {
                     const f32x16 b = bias_tile(L.b2 + 32 * j, h);
                     for (int i = 0; i < 16; ++i) R[j][i] += b[i];
                 }
             dma_wait_all();
+            STAMP(15);
             __syncthreads();  // fetched tiles landed; this chunk's tiles are free
+            STAMP(16);
         };
 #pragma nounroll
-        for (int c = 0; c < FF / FFC - 2; ++c) chunk(c, std::integral_constant<int, 0>{});
-        chunk(FF / FFC - 2, std::integral_constant<int, 1>{});
-        chunk(FF / FFC - 1, std::integral_constant<int, 2>{});
+        for (int c = 0; c < FF / FFC - 2; c += 2) {
+            chunk(c, std::integral_constant<int, 0>{}, hB0, hB1, hA0, hA1);
+            chunk(c + 1, std::integral_constant<int, 0>{}, hA0, hA1, hB0, hB1);
+        }
+        chunk(FF / FFC - 2, std::integral_constant<int, 1>{}, hB0, hB1, hA0, hA1);
+        chunk(FF / FFC - 1, std::integral_constant<int, 2>{}, hA0, hA1, hB0, hB1);
     }
 
+    STAMP(17);
     if (MODE == MODE_HEAD) {
-        // ---- last layer, K/V only: LayerNorm, K^T and V^T of every head -> HBM, CLS residual row -> HBM
+        // ---- last layer, K/V only: LayerNorm, K^T and V^T of every head -> HBM, CLS residual row -> HBM.
+        // On entry the in_proj tiles of heads 0 and 1 of this layer are in LDS or in flight (previous layer's tail / prologue).
         const unsigned lwl = (unsigned)(n_layers - 1) * (unsigned)(W_LAYER * 2);
-        auto dma_kv = [&](int hd) __attribute__((always_inline)) { dma_qkv(lwl, hd, 1, 3); };
-        __syncthreads();  // the last feed-forward tiles are no longer read
-        dma_kv(0);
         if (tok_valid && tc == 0) {
             float *dst = ws_r + (board0 + tb) * D;
             for (int j = 0; j < 8; ++j)
@@ -651,32 +741,57 @@ k_encoder_main(const uint8_t *__restrict__ boards, const float *__restrict__ tab
                     *reinterpret_cast<f32x4 *>(dst + 32 * j + 8 * g + 4 * h) = v;
                 }
         }
-        bf16x8 xn[16];
         layer_norm(R, xn);
         dma_wait_all();
         __syncthreads();
-#pragma nounroll
-        for (int hd = 0; hd < NH; ++hd) {
-            if (hd + 1 < NH) dma_kv(hd + 1);  // the other buffer: its last reader finished before the previous barrier
-            const char *t = wqkv(hd);
-            const f32x16 zero = {0};
-            f32x16 ka = gemm_tile<32, 16>(t + TILE, lo, 0, xn, zero);
-            f32x16 va = gemm_tile<32, 16>(t + 2 * TILE, lo, 0, xn, zero);
-            pipe_mfma<32>();
-            sched_fence();
+        // K^T and V^T of head hd from the k / v tiles in buffer (hd & 1): 32 steps.  FETCH: every fourth step one piece of head
+        // hd+1's k / v tiles goes into the other buffer (free since the barrier that ended iteration hd-1); heads 0 and 1
+        // are already there.
+        bf16x8 kst[2], vst[2];  // head hd-1's K^T / V^T, stored one iteration late: the wait at the end of an iteration then
+                                // covers stores issued a whole chain earlier instead of stalling on HBM write latency
+        auto store_head = [&](int hd) __attribute__((always_inline)) {
             if (tok_valid) {
                 const size_t off = (size_t)(board0 + tb) * KV_ELEMS + ((size_t)hd * SEQ + tc) * HD + 16 * h;
-                bf16x8 f[2];
-                frag_from_acc(ka, f);
-                *reinterpret_cast<bf16x8 *>(ws_k + off) = f[0];
-                *reinterpret_cast<bf16x8 *>(ws_k + off + 8) = f[1];
-                frag_from_acc(va, f);
-                *reinterpret_cast<bf16x8 *>(ws_v + off) = f[0];
-                *reinterpret_cast<bf16x8 *>(ws_v + off + 8) = f[1];
+                *reinterpret_cast<bf16x8 *>(ws_k + off) = kst[0];
+                *reinterpret_cast<bf16x8 *>(ws_k + off + 8) = kst[1];
+                *reinterpret_cast<bf16x8 *>(ws_v + off) = vst[0];
+                *reinterpret_cast<bf16x8 *>(ws_v + off + 8) = vst[1];
             }
+        };
+        auto kv_head = [&](int hd, auto fetch_tag, auto store_tag) __attribute__((always_inline)) {
+            constexpr bool FETCH = decltype(fetch_tag)::value, STORE = decltype(store_tag)::value;
+            if constexpr (STORE) store_head(hd - 1);
+            const char *t = wqkv(hd);
+            f32x16 ka2 = {0}, va2 = {0};
+            bf16x8 a[PD];
+            static_for<0, PD>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                a[i] = load_w<32>(t + (1 + i / 16) * TILE, lo, 0, i % 16);
+            });
+            sched_fence();
+            static_for<0, 32>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 16) ka2 = mfma(a[i % PD], xn[i % 16], ka2);
+                else va2 = mfma(a[i % PD], xn[i % 16], va2);
+                if constexpr (i + PD < 32) a[i % PD] = load_w<32>(t + (1 + (i + PD) / 16) * TILE, lo, 0, (i + PD) % 16);
+                if constexpr (FETCH && i % 3 == 0 && i < 24) dma_qkv1(lwl, hd + 1, 4 + i / 3);
+                if constexpr (i >= 20 && i < 22)
+                    for (int j = 0; j < 8; ++j) kst[i - 20][j] = (__bf16)ka2[8 * (i - 20) + j];
+                sched_fence();
+            });
+            frag_from_acc(va2, vst);
             dma_wait_all();
-            __syncthreads();
-        }
+            __syncthreads();  // head hd's tiles are free, head hd+1's have landed
+        };
+        kv_head(0, std::false_type{}, std::false_type{});
+#pragma nounroll
+        for (int hd = 1; hd < NH - 1; ++hd) kv_head(hd, std::true_type{}, std::true_type{});
+        kv_head(NH - 1, std::false_type{}, std::true_type{});
+        store_head(NH - 1);
+        STAMP(18);
+#ifdef G2048_STAMPS
+        stamps.flush(lane, w);
+#endif
         return;
     }
 
@@ -847,6 +962,17 @@ k_encoder_tail(const __bf16 *__restrict__ wblob, const float *__restrict__ pblob
 }
 
 }  // namespace
+
+#ifdef G2048_STAMPS
+extern "C" int g2048_debug_stamps(unsigned long long *out /*host [24]*/, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * N_STAMPS) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[N_STAMPS] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return N_STAMPS;
+}
+#endif
 
 extern "C" int64_t g2048_policy_encoder_workspace_bytes(int64_t B) {
     return B <= 0 ? 0 : B * (2 * KV_ELEMS * (int64_t)sizeof(__bf16) + D * (int64_t)sizeof(float));

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 passes for the rollout encoder pair (k_encoder<HEAD>, k_encoder<TAIL>) at 65536 boards: kernel trace + two PMC passes
+# rocprofv3 passes for the rollout encoder pair (k_encoder_main<HEAD>, k_encoder_tail) at 65536 boards: kernel trace + two PMC passes
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf /tmp/pe && mkdir -p gpurun_out/enc
@@ -11,12 +11,12 @@ for p in p1 p2; do cp /tmp/pe/$p/*/*_counter_collection.csv gpurun_out/enc/$p.cs
 python3 - <<'PY'
 import csv, collections, json
 out = {}
-for mode, tag in (("ILi1E", "head"), ("ILi2E", "tail"), ("ILi0E", "single")):
+for pats, tag in ((("mainILi1E", "k_encoder_main<1>"), "head"), (("k_encoder_tail",), "tail"), (("mainILi0E", "k_encoder_main<0>"), "single")):
     d = {}
     for p in ("p1", "p2"):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f"gpurun_out/enc/{p}.csv")):
-            if "k_encoder" in r["Kernel_Name"] and (mode in r["Kernel_Name"] or f"<{mode[3]}>" in r["Kernel_Name"]):
+            if any(pat in r["Kernel_Name"] for pat in pats):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             d[k] = sum(v) / len(v)
@@ -29,8 +29,8 @@ for mode, tag in (("ILi1E", "head"), ("ILi2E", "tail"), ("ILi0E", "single")):
 for r in csv.DictReader(open("gpurun_out/enc/kernel_stats.csv")):
     if "k_encoder" in r["Name"]:
         out.setdefault("kernel_trace", {})[r["Name"][:60]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])}
-out["_note"] = ("rocprofv3 on tools/prof_fused.py 65536 (4 layers): k_encoder<1> = HEAD (layers 0-2 + K/V of layer 3), <2> = TAIL "
-                "(CLS-only rest of layer 3, 128 boards per workgroup), <0> = single-kernel form; PMC in two separate passes; "
+out["_note"] = ("rocprofv3 on tools/prof_fused.py 65536 (4 layers): k_encoder_main<1> = HEAD (layers 0-2 + K/V of layer 3), "
+                "k_encoder_tail = CLS-only rest of layer 3 (128 boards per workgroup), k_encoder_main<0> = single-kernel form; PMC in two separate passes; "
                 "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)")
 json.dump(out, open("gpurun_out/enc/encoder_pmc.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
