@@ -190,7 +190,16 @@ __global__ void __launch_bounds__(kBlock) k_rollout_fused(const StepKeyTable key
     if ((threadIdx.x & 63) == 0 && live) atomicAdd(live_count, (u32)__popcll(live));
 }
 
-template <int MODE>
+// jax.random.fold_in(key, 0xFFFFFFFF): the per-step "reset" sub-key of the auto-reset mode, derived from the step
+// sub-key without advancing the host's key chain (fold_in is one threefry block over the counter (0, data))
+__device__ __forceinline__ void reset_subkey(u32 ss0, u32 ss1, u32 &r0, u32 &r1) { tf2x32(ss0, ss1, 0u, 0xFFFFFFFFu, r0, r1); }
+
+// AUTO = 0: the reference's lock-step semantics (finished envs freeze; fill_frozen writes their frozen frames).
+// AUTO = 1: fixed-horizon throughput mode (replaces the lock-step of src/runs/batch_runner.py:117): every
+//   lane steps at every call; a lane whose step terminates is re-initialised at once from its own key
+//   split(fold_in(step_sub, 0xFFFFFFFF), B_total)[g], so row t+1 of the trajectory starts its next episode.  The row of
+//   the terminal step keeps done_after = 1 (the episode boundary for GAE); ep_len counts the steps of the running episode.
+template <int MODE, int AUTO>
 __global__ void __launch_bounds__(kBlock) k_policy_step(u32 as0, u32 as1, u32 ss0, u32 ss1, const float *logits,
                                                         const float *values, int use_mask, int sample, int64_t t,
                                                         uint8_t *boards, uint8_t *masks, uint8_t *done,
@@ -202,8 +211,8 @@ __global__ void __launch_bounds__(kBlock) k_policy_step(u32 as0, u32 as1, u32 ss
     const bool in_range = i < B;
     u32 d = 1;
     if (in_range) {
-        d = done[i];
-        if (fill_frozen || d == 0) {
+        d = AUTO ? 0u : done[i];
+        if (AUTO || fill_frozen || d == 0) {
             Board bd = load_board(boards, i);
             u32 m = masks[i];
             const u32 g = env0 + (u32)i;
@@ -223,7 +232,19 @@ __global__ void __launch_bounds__(kBlock) k_policy_step(u32 as0, u32 as1, u32 ss
             tr_rewards[o] = r;
             tr_logp[o] = lp;
             tr_values[o] = values[i];
-            if (was_live) {
+            if (AUTO) {
+                int32_t len = ep_len[i] + 1;
+                if (d) {  // terminal step: the lane starts its next episode now
+                    u32 r0, r1;
+                    reset_subkey(ss0, ss1, r0, r1);
+                    split_at<MODE>(r0, r1, B_total, g, k0, k1);
+                    env_init<MODE>(bd, m, k0, k1);
+                    len = 0;
+                }
+                store_board(boards, i, bd);
+                masks[i] = (uint8_t)m;
+                ep_len[i] = len;
+            } else if (was_live) {
                 store_board(boards, i, bd);
                 masks[i] = (uint8_t)m;
                 done[i] = (uint8_t)d;
@@ -231,8 +252,10 @@ __global__ void __launch_bounds__(kBlock) k_policy_step(u32 as0, u32 as1, u32 ss
             }
         }
     }
-    const unsigned long long live = __ballot(in_range && d == 0);
-    if ((threadIdx.x & 63) == 0 && live) atomicAdd(live_count, (u32)__popcll(live));
+    if (!AUTO) {
+        const unsigned long long live = __ballot(in_range && d == 0);
+        if ((threadIdx.x & 63) == 0 && live) atomicAdd(live_count, (u32)__popcll(live));
+    }
 }
 
 // ---------------------------------------------------------------------------------------- GAE / buffer
@@ -247,6 +270,30 @@ __global__ void __launch_bounds__(kBlock) k_gae_tb(const float *rew, const float
     float last_gae = 0.0f, last_v = 0.0f;
     for (int64_t t = n - 1; t >= 0; --t) {
         const int64_t o = t * B + e;
+        const float r = rew[o], v = val[o];
+        const float delta = __fsub_rn(__fadd_rn(r, __fmul_rn(g, last_v)), v);
+        last_gae = __fadd_rn(delta, __fmul_rn(gl, last_gae));
+        adv[o] = last_gae;
+        ret[o] = __fadd_rn(last_gae, v);
+        last_v = v;
+    }
+}
+
+// The same scan for fixed-horizon rollouts: every lane has T steps, episode boundaries are the done_after bits of tr_meta
+// (the reference's reset at terminations[step]), and the scan starts from V(s_T) = last_val[e] -- the value of the state the
+// horizon cut off (ignored when step T-1 was terminal).
+__global__ void __launch_bounds__(kBlock) k_gae_tb_boot(const float *rew, const float *val, const uint8_t *meta,
+                                                        const float *last_val, float *adv, float *ret, int64_t T,
+                                                        int64_t B, float g, float gl) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= B) return;
+    float last_gae = 0.0f, last_v = last_val[e];
+    for (int64_t t = T - 1; t >= 0; --t) {
+        const int64_t o = t * B + e;
+        if ((meta[o] >> 6) & 1u) {
+            last_v = 0.0f;
+            last_gae = 0.0f;
+        }
         const float r = rew[o], v = val[o];
         const float delta = __fsub_rn(__fadd_rn(r, __fmul_rn(g, last_v)), v);
         last_gae = __fadd_rn(delta, __fmul_rn(gl, last_gae));
@@ -280,10 +327,11 @@ __global__ void __launch_bounds__(kBlock) k_gae_flat(const float *rew, const flo
 // are contiguous (the strided reads are the cost of the reference's env-major order).
 __global__ void __launch_bounds__(kBlock) k_compact(const uint8_t *tr_boards, const uint8_t *tr_meta,
                                                     const float *tr_rewards, const float *tr_logp,
-                                                    const float *tr_values, const int32_t *ep_len,
-                                                    const int64_t *offsets, uint8_t *out_boards, uint8_t *out_actions,
-                                                    uint8_t *out_masks, float *out_rewards, float *out_logp,
-                                                    float *out_values, uint8_t *out_terms, int64_t T, int64_t B) {
+                                                    const float *tr_values, const float *tr_adv, const float *tr_ret,
+                                                    const int32_t *ep_len, const int64_t *offsets, uint8_t *out_boards,
+                                                    uint8_t *out_actions, uint8_t *out_masks, float *out_rewards,
+                                                    float *out_logp, float *out_values, float *out_adv, float *out_ret,
+                                                    uint8_t *out_terms, int64_t T, int64_t B) {
     const int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (e >= B) return;
@@ -300,6 +348,8 @@ __global__ void __launch_bounds__(kBlock) k_compact(const uint8_t *tr_boards, co
         out_rewards[dst] = tr_rewards[src];
         if (out_logp) out_logp[dst] = tr_logp[src];
         if (out_values) out_values[dst] = tr_values[src];
+        if (out_adv) out_adv[dst] = tr_adv[src];
+        if (out_ret) out_ret[dst] = tr_ret[src];
     }
 }
 
@@ -439,33 +489,71 @@ int g2048_rollout_fused(const uint32_t *step_subs, int n_steps, int64_t t0, uint
     return finish();
 }
 
+static int policy_step_impl(int autoreset, uint32_t act_sub0, uint32_t act_sub1, uint32_t step_sub0, uint32_t step_sub1,
+                            const float *logits, const float *values, int use_mask, int sample, int64_t t, uint8_t *boards,
+                            uint8_t *masks, uint8_t *done, int32_t *ep_len, uint8_t *tr_boards, uint8_t *tr_meta,
+                            float *tr_rewards, float *tr_logp, float *tr_values, int64_t B, int64_t B_total, int64_t env0,
+                            int fill_frozen, int rng_mode, uint32_t *live_count, void *stream) {
+    if (!logits || !values || t < 0 || !boards || !masks || !ep_len || !tr_boards || !tr_meta || !tr_rewards || !tr_logp ||
+        !tr_values || B <= 0 || env0 < 0 || B_total > kMaxEnvs || env0 + B > B_total || bad_mode(rng_mode))
+        return G2048_EINVAL;
+    if (!autoreset && (!done || !live_count)) return G2048_EINVAL;
+    if (((uintptr_t)boards & 15) || ((uintptr_t)tr_boards & 15) || ((uintptr_t)logits & 15)) return G2048_EINVAL;
+    const u32 bt = (u32)B_total, e0 = (u32)env0;
+#define G2048_PS(M, A)                                                                                                   \
+    G2048_LAUNCH((k_policy_step<M, A>), B, stream, act_sub0, act_sub1, step_sub0, step_sub1, logits, values, use_mask,  \
+                 sample, t, boards, masks, done, ep_len, tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, B, bt, e0, \
+                 fill_frozen, live_count)
+    if (rng_mode) {
+        if (autoreset) G2048_PS(1, 1);
+        else G2048_PS(1, 0);
+    } else {
+        if (autoreset) G2048_PS(0, 1);
+        else G2048_PS(0, 0);
+    }
+#undef G2048_PS
+    return finish();
+}
+
 int g2048_policy_step(uint32_t act_sub0, uint32_t act_sub1, uint32_t step_sub0, uint32_t step_sub1,
                       const float *logits, const float *values, int use_mask, int sample, int64_t t,
                       uint8_t *boards, uint8_t *masks, uint8_t *done, int32_t *ep_len, uint8_t *tr_boards,
                       uint8_t *tr_meta, float *tr_rewards, float *tr_logp, float *tr_values, int64_t B,
                       int64_t B_total, int64_t env0, int fill_frozen, int rng_mode, uint32_t *live_count,
                       void *stream) {
-    if (!logits || !values || t < 0 || !boards || !masks || !done || !ep_len || !tr_boards || !tr_meta ||
-        !tr_rewards || !tr_logp || !tr_values || !live_count || B <= 0 || env0 < 0 || B_total > kMaxEnvs ||
-        env0 + B > B_total || bad_mode(rng_mode))
-        return G2048_EINVAL;
-    if (((uintptr_t)boards & 15) || ((uintptr_t)tr_boards & 15) || ((uintptr_t)logits & 15)) return G2048_EINVAL;
-    const u32 bt = (u32)B_total, e0 = (u32)env0;
-    if (rng_mode)
-        G2048_LAUNCH(k_policy_step<1>, B, stream, act_sub0, act_sub1, step_sub0, step_sub1, logits, values, use_mask,
-                     sample, t, boards, masks, done, ep_len, tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, B,
-                     bt, e0, fill_frozen, live_count);
-    else
-        G2048_LAUNCH(k_policy_step<0>, B, stream, act_sub0, act_sub1, step_sub0, step_sub1, logits, values, use_mask,
-                     sample, t, boards, masks, done, ep_len, tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, B,
-                     bt, e0, fill_frozen, live_count);
-    return finish();
+    return policy_step_impl(0, act_sub0, act_sub1, step_sub0, step_sub1, logits, values, use_mask, sample, t, boards, masks,
+                            done, ep_len, tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, B, B_total, env0, fill_frozen,
+                            rng_mode, live_count, stream);
+}
+
+int g2048_policy_step_autoreset(uint32_t act_sub0, uint32_t act_sub1, uint32_t step_sub0, uint32_t step_sub1,
+                                const float *logits, const float *values, int use_mask, int sample, int64_t t,
+                                uint8_t *boards, uint8_t *masks, int32_t *ep_len, uint8_t *tr_boards, uint8_t *tr_meta,
+                                float *tr_rewards, float *tr_logp, float *tr_values, int64_t B, int64_t B_total,
+                                int64_t env0, int rng_mode, void *stream) {
+    return policy_step_impl(1, act_sub0, act_sub1, step_sub0, step_sub1, logits, values, use_mask, sample, t, boards, masks,
+                            nullptr, ep_len, tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, B, B_total, env0, 0,
+                            rng_mode, nullptr, stream);
+}
+
+int g2048_reset_key(uint32_t step_sub0, uint32_t step_sub1, uint32_t *out /*host [2]*/) {
+    if (!out) return G2048_EINVAL;
+    tf2x32(step_sub0, step_sub1, 0u, 0xFFFFFFFFu, out[0], out[1]);
+    return 0;
 }
 
 int g2048_gae_tb(const float *tr_rewards, const float *tr_values, const int32_t *ep_len, float *tr_adv,
                  float *tr_ret, int64_t T, int64_t B, double gamma, double lam, void *stream) {
     if (!tr_rewards || !tr_values || !ep_len || !tr_adv || !tr_ret || T <= 0 || B <= 0) return G2048_EINVAL;
     G2048_LAUNCH(k_gae_tb, B, stream, tr_rewards, tr_values, ep_len, tr_adv, tr_ret, T, B, (float)gamma,
+                 (float)(gamma * lam));
+    return finish();
+}
+
+int g2048_gae_tb_boot(const float *tr_rewards, const float *tr_values, const uint8_t *tr_meta, const float *last_values,
+                      float *tr_adv, float *tr_ret, int64_t T, int64_t B, double gamma, double lam, void *stream) {
+    if (!tr_rewards || !tr_values || !tr_meta || !last_values || !tr_adv || !tr_ret || T <= 0 || B <= 0) return G2048_EINVAL;
+    G2048_LAUNCH(k_gae_tb_boot, B, stream, tr_rewards, tr_values, tr_meta, last_values, tr_adv, tr_ret, T, B, (float)gamma,
                  (float)(gamma * lam));
     return finish();
 }
@@ -478,16 +566,18 @@ int g2048_gae_flat(const float *rewards, const float *values, const uint8_t *ter
 }
 
 int g2048_compact(const uint8_t *tr_boards, const uint8_t *tr_meta, const float *tr_rewards, const float *tr_logp,
-                  const float *tr_values, const int32_t *ep_len, const int64_t *offsets, uint8_t *out_boards,
-                  uint8_t *out_actions, uint8_t *out_masks, float *out_rewards, float *out_logp, float *out_values,
-                  uint8_t *out_terms, int64_t T, int64_t B, void *stream) {
+                  const float *tr_values, const float *tr_adv, const float *tr_ret, const int32_t *ep_len,
+                  const int64_t *offsets, uint8_t *out_boards, uint8_t *out_actions, uint8_t *out_masks, float *out_rewards,
+                  float *out_logp, float *out_values, float *out_adv, float *out_ret, uint8_t *out_terms, int64_t T,
+                  int64_t B, void *stream) {
     if (!tr_boards || !tr_meta || !tr_rewards || !ep_len || !offsets || !out_boards || !out_actions || !out_masks ||
         !out_rewards || !out_terms || T <= 0 || B <= 0)
         return G2048_EINVAL;
-    if ((out_logp && !tr_logp) || (out_values && !tr_values)) return G2048_EINVAL;
+    if ((out_logp && !tr_logp) || (out_values && !tr_values) || (out_adv && !tr_adv) || (out_ret && !tr_ret)) return G2048_EINVAL;
     if (((uintptr_t)tr_boards & 15) || ((uintptr_t)out_boards & 15)) return G2048_EINVAL;
-    G2048_LAUNCH(k_compact, B * 64, stream, tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, ep_len, offsets,
-                 out_boards, out_actions, out_masks, out_rewards, out_logp, out_values, out_terms, T, B);
+    G2048_LAUNCH(k_compact, B * 64, stream, tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, tr_adv, tr_ret, ep_len,
+                 offsets, out_boards, out_actions, out_masks, out_rewards, out_logp, out_values, out_adv, out_ret, out_terms,
+                 T, B);
     return finish();
 }
 

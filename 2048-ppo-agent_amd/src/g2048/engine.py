@@ -60,6 +60,40 @@ class Trajectory:
         return int(self.ep_len.sum().item())
 
 
+@dataclass
+class FixedTrajectory:
+    """Fixed-horizon trajectory (throughput mode): every lane has exactly T rows; a lane whose step terminated started
+    its next episode in the following row, ``terms`` marks the boundaries."""
+
+    boards: torch.Tensor  # u8 [T, B, 16]  board before step t
+    meta: torch.Tensor  # u8 [T, B]      action | mask_before << 2 | done_after << 6
+    rewards: torch.Tensor  # f32 [T, B]
+    log_probs: torch.Tensor  # f32 [T, B]
+    values: torch.Tensor  # f32 [T, B]
+    final_boards: torch.Tensor  # u8 [B, 16]  state after step T-1 (a fresh board where that step was terminal)
+    final_masks: torch.Tensor  # u8 [B]
+    ep_len: torch.Tensor  # i32 [B] steps of the episode that is still running after step T-1
+    ep_len_before: torch.Tensor  # i32 [B] the same counter before step 0 (episodes continue across rollouts)
+    T: int
+    B: int
+
+    actions = Trajectory.actions
+    masks = Trajectory.masks
+    terms = Trajectory.terms
+
+    def num_steps(self) -> int:
+        return self.T * self.B
+
+    def finished_episode_lengths(self) -> torch.Tensor:
+        """i32 [n]: lengths of the episodes that ended inside this rollout (counting their steps of earlier rollouts)."""
+        done = self.terms.bool()  # [T, B]
+        t = torch.arange(self.T, device=done.device, dtype=torch.int32)[:, None].expand_as(done)
+        last = torch.cummax(torch.where(done, t, torch.full_like(t, -1)), dim=0).values  # last terminal row <= t
+        prev = torch.cat([torch.full_like(last[:1], -1), last[:-1]], dim=0)  # last terminal row < t
+        length = torch.where(prev >= 0, t - prev, t + 1 + self.ep_len_before[None, :])
+        return length[done]
+
+
 class RolloutEngine:
     """One shard of a lock-step batch: envs [env0, env0 + B) of B_total, on one GPU."""
 
@@ -78,6 +112,7 @@ class RolloutEngine:
         # costs milliseconds; the rollout itself is ~1 ms at 65 536 boards)
         self._ws = None
         self._ws_key = None
+        self._fixed = None  # persistent env state of the fixed-horizon mode: (boards, masks, ep_len, B, B_total, env0)
         # multi-GPU: a callable int -> int returning the maximum over all ranks.  The reference's key chain
         # advances by 1 + 2 T splits per rollout with T the longest episode of the WHOLE batch, so shards agree
         # on it before advancing their (identical) host-side chains.
@@ -217,6 +252,38 @@ class RolloutEngine:
             if compact and n_live < B:
                 live_idx = torch.nonzero(done == 0).flatten()
         return self._finish(bufs, state, init_boards, B, fill_frozen, key0, None)
+
+
+    # ------------------------------------------------------------------ fixed horizon, per-lane auto-reset
+    def rollout_policy_fixed(self, B: int, T: int, policy_fn: Callable, use_mask: bool, sample: bool = True,
+                             B_total: Optional[int] = None, env0: int = 0, restart: bool = False) -> FixedTrajectory:
+        """T lock-steps of B always-live lanes (throughput mode; no reference counterpart: it replaces the
+        ``while not all terminated`` of src/runs/batch_runner.py:117).  A lane whose step terminates is re-initialised in
+        the same kernel from ``split(fold_in(step_sub, 0xFFFFFFFF), B_total)[env]``; the host key chain advances as in the
+        reference (init split at the first call, then act/step splits per lock-step).  Env state persists across calls
+        (``restart`` re-initialises it).  No host synchronisation inside the loop."""
+        if B <= 0 or T <= 0:
+            raise ValueError("batch_size and horizon must be positive")
+        B_total = B if B_total is None else int(B_total)
+        st = self._fixed
+        if restart or st is None or st[3:] != (B, B_total, env0):
+            self.key, sub = nv.chain_keys(self.key, 1, self.rng_mode)
+            boards, masks, done, ep_len = self._alloc_state(B)
+            nv.reset_fused(sub[0], boards, masks, done, ep_len, B_total, env0, self.rng_mode)
+            self._fixed = st = (boards, masks, ep_len, B, B_total, env0)
+        boards, masks, ep_len = st[:3]
+        ep_before = ep_len.clone()
+        bufs = self._alloc_traj(T, B, with_logp=True, with_values=True)
+        self.key, subs = nv.chain_keys(self.key, 2 * T, self.rng_mode)
+        for t in range(T):
+            logits, values = policy_fn(boards, masks)
+            nv.policy_step_autoreset(subs[2 * t], subs[2 * t + 1], logits.to(torch.float32).contiguous(),
+                                     values.to(torch.float32).reshape(-1).contiguous(), use_mask, sample, t, boards, masks,
+                                     ep_len, bufs["boards"], bufs["meta"], bufs["rewards"], bufs["logp"], bufs["values"],
+                                     B_total, env0, self.rng_mode)
+        return FixedTrajectory(boards=bufs["boards"][:T], meta=bufs["meta"][:T], rewards=bufs["rewards"][:T],
+                               log_probs=bufs["logp"][:T], values=bufs["values"][:T], final_boards=boards, final_masks=masks,
+                               ep_len=ep_len, ep_len_before=ep_before, T=T, B=B)
 
 
 # ---------------------------------------------------------------------------------------------------

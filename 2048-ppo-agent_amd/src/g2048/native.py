@@ -38,9 +38,13 @@ SIGNATURES = {
                             _i32, _i32, _i32, _vp, _vp],
     "g2048_policy_step": [_u32, _u32, _u32, _u32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp],
+    "g2048_policy_step_autoreset": [_u32, _u32, _u32, _u32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _i64, _i64, _i64, _i32, _vp],
+    "g2048_reset_key": [_u32, _u32, _vp],
     "g2048_gae_tb": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _dbl, _dbl, _vp],
+    "g2048_gae_tb_boot": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _dbl, _dbl, _vp],
     "g2048_gae_flat": [_vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp],
-    "g2048_compact": [_vp] * 14 + [_i64, _i64, _vp],
+    "g2048_compact": [_vp] * 18 + [_i64, _i64, _vp],
     "g2048_policy_encoder_workspace_bytes": [_i64],
     "g2048_policy_encoder": [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp],
     "g2048_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, C.c_float,
@@ -87,7 +91,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
             fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_workspace_bytes")) else C.c_int
-        if lib.g2048_abi_version() != 1:
+        if lib.g2048_abi_version() != 2:
             raise NativeError("libg2048.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -228,6 +232,34 @@ def policy_step(act_sub, step_sub, logits, values, use_mask, sample, t: int, boa
                                     _dev(live_count, i32, 1, "live_count"), _stream()), "g2048_policy_step")
 
 
+def policy_step_autoreset(act_sub, step_sub, logits, values, use_mask, sample, t: int, boards, masks, ep_len, tr_boards,
+                          tr_meta, tr_rewards, tr_logp, tr_values, B_total: int, env0: int, rng_mode: int):
+    """One lock-step of the fixed-horizon mode: every lane steps, a terminated lane starts its next episode at once."""
+    B = masks.numel()
+    need = (t + 1) * B
+    _check(load().g2048_policy_step_autoreset(
+        int(act_sub[0]), int(act_sub[1]), int(step_sub[0]), int(step_sub[1]), _dev(logits, f32, 4 * B, "logits"),
+        _dev(values, f32, B, "values"), int(bool(use_mask)), int(bool(sample)), t, _dev(boards, u8, 16 * B, "boards"),
+        _dev(masks, u8, B, "masks"), _dev(ep_len, i32, B, "ep_len"), _dev(tr_boards, u8, 16 * need, "tr_boards"),
+        _dev(tr_meta, u8, need, "tr_meta"), _dev(tr_rewards, f32, need, "tr_rewards"), _dev(tr_logp, f32, need, "tr_logp"),
+        _dev(tr_values, f32, need, "tr_values"), B, B_total, env0, rng_mode, _stream()), "g2048_policy_step_autoreset")
+
+
+def reset_key(step_sub) -> np.ndarray:
+    """jax.random.fold_in(step_sub, 0xFFFFFFFF): the reset sub-key of one lock-step of the fixed-horizon mode."""
+    out = np.empty(2, np.uint32)
+    _check(load().g2048_reset_key(int(step_sub[0]), int(step_sub[1]), out.ctypes.data), "g2048_reset_key")
+    return out
+
+
+def gae_tb_boot(tr_rewards, tr_values, tr_meta, last_values, tr_adv, tr_ret, T: int, B: int, gamma: float, lam: float):
+    n = T * B
+    _check(load().g2048_gae_tb_boot(_dev(tr_rewards, f32, n, "tr_rewards"), _dev(tr_values, f32, n, "tr_values"),
+                                    _dev(tr_meta, u8, n, "tr_meta"), _dev(last_values, f32, B, "last_values"),
+                                    _dev(tr_adv, f32, n, "tr_adv"), _dev(tr_ret, f32, n, "tr_ret"), T, B, float(gamma),
+                                    float(lam), _stream()), "g2048_gae_tb_boot")
+
+
 def gae_tb(tr_rewards, tr_values, ep_len, tr_adv, tr_ret, T: int, B: int, gamma: float, lam: float):
     n = T * B
     _check(load().g2048_gae_tb(_dev(tr_rewards, f32, n, "tr_rewards"), _dev(tr_values, f32, n, "tr_values"),
@@ -244,16 +276,19 @@ def gae_flat(rewards, values, terms, adv, ret, gamma: float, lam: float):
 
 
 def compact(tr_boards, tr_meta, tr_rewards, tr_logp, tr_values, ep_len, offsets, out_boards, out_actions, out_masks,
-            out_rewards, out_logp, out_values, out_terms, T: int, B: int, N: int):
+            out_rewards, out_logp, out_values, out_terms, T: int, B: int, N: int, tr_adv=None, tr_ret=None, out_adv=None,
+            out_ret=None):
     n = T * B
     _check(load().g2048_compact(
         _dev(tr_boards, u8, 16 * n, "tr_boards"), _dev(tr_meta, u8, n, "tr_meta"),
         _dev(tr_rewards, f32, n, "tr_rewards"), _dev(tr_logp, f32, n, "tr_logp", optional=True),
-        _dev(tr_values, f32, n, "tr_values", optional=True), _dev(ep_len, i32, B, "ep_len"),
+        _dev(tr_values, f32, n, "tr_values", optional=True), _dev(tr_adv, f32, n, "tr_adv", optional=True),
+        _dev(tr_ret, f32, n, "tr_ret", optional=True), _dev(ep_len, i32, B, "ep_len"),
         _dev(offsets, i64, B, "offsets"), _dev(out_boards, u8, 16 * N, "out_boards"),
         _dev(out_actions, u8, N, "out_actions"), _dev(out_masks, u8, N, "out_masks"),
         _dev(out_rewards, f32, N, "out_rewards"), _dev(out_logp, f32, N, "out_logp", optional=True),
-        _dev(out_values, f32, N, "out_values", optional=True), _dev(out_terms, u8, N, "out_terms"), T, B,
+        _dev(out_values, f32, N, "out_values", optional=True), _dev(out_adv, f32, N, "out_adv", optional=True),
+        _dev(out_ret, f32, N, "out_ret", optional=True), _dev(out_terms, u8, N, "out_terms"), T, B,
         _stream()), "g2048_compact")
 
 

@@ -74,8 +74,13 @@ class PPODataset(Dataset):
         get = lambda k: (buffer_data[k] if isinstance(buffer_data[k], torch.Tensor)
                          else torch.from_numpy(np.ascontiguousarray(buffer_data[k]))).to(device=dev, dtype=torch.float32)
         self.rewards, self.values, self.log_probs = get("rewards"), get("values"), get("log_probs")
-        self.raw_advantages, self.raw_returns = compute_gae(self.rewards, self.values, self.terminations,
-                                                           gamma, lambda_gae)
+        if "raw_advantages" in buffer_data and "raw_returns" in buffer_data:
+            # the buffer already ran the scan on the coalesced [T][B] trajectory (RolloutBuffer.store_trajectory with
+            # gamma / lambda, or the bootstrapped scan of the fixed-horizon mode)
+            self.raw_advantages, self.raw_returns = get("raw_advantages"), get("raw_returns")
+        else:
+            self.raw_advantages, self.raw_returns = compute_gae(self.rewards, self.values, self.terminations,
+                                                               gamma, lambda_gae)
         self.advantages = zscore(self.raw_advantages, group)
         self.returns = zscore(self.raw_returns, group)
         self.total_length = int(self.rewards.shape[0])

@@ -164,7 +164,8 @@ class PPOTrainer:
                  mixed_precision: Optional[Literal["float16", "bfloat16"]] = "bfloat16",
                  max_samples_per_epoch: int = None, shuffle_on_reset: bool = False,
                  rollout_amp: Optional[bool] = None,
-                 log_dir: str = "logs", use_hip_graph: Optional[bool] = None):
+                 log_dir: str = "logs", use_hip_graph: Optional[bool] = None, rollout_mode: Optional[str] = None,
+                 rollout_horizon: Optional[int] = None):
         self.agent = agent.to(device)
         self.batch_runner = batch_runner
         self.rollout_buffer = rollout_buffer
@@ -192,6 +193,19 @@ class PPOTrainer:
         if rollout_amp is None:
             rollout_amp = os.environ.get("G2048_ROLLOUT_AMP", "0").strip().lower() in ("1", "true", "yes", "on")
         self.rollout_amp = bool(rollout_amp) and self.use_amp
+        # How collect_rollouts gathers experience.  "episodes" (default) is the reference: lock-step batches of complete
+        # episodes (src/runs/batch_runner.py:117), finished envs idle until the slowest one ends.  "fixed_horizon" is the
+        # throughput mode: every env steps rollout_horizon times per batch, an env whose episode ends starts the next one at
+        # once, and GAE bootstraps from V(s_T) where the horizon cut an episode.  For the unmodified reference CLI:
+        # G2048_ROLLOUT_MODE=fixed_horizon [G2048_ROLLOUT_HORIZON=128].
+        if rollout_mode is None:
+            rollout_mode = os.environ.get("G2048_ROLLOUT_MODE", "episodes").strip().lower()
+        if rollout_mode not in ("episodes", "fixed_horizon"):
+            raise ValueError(f"rollout_mode must be 'episodes' or 'fixed_horizon', got {rollout_mode!r}")
+        self.rollout_mode = rollout_mode
+        if rollout_horizon is None:
+            rollout_horizon = int(os.environ.get("G2048_ROLLOUT_HORIZON", "128"))
+        self.rollout_horizon = int(rollout_horizon)
 
         opt = configure_bert_optimizers(self.agent, steps=max_steps, **dict(optimizer_param_dict))
         self.optimizer = opt["optimizer"]
@@ -299,10 +313,21 @@ class PPOTrainer:
             self.batch_runner._engine.global_max = self._global_max
         total_episodes = 0
         ep_rew, ep_len = [], []
+        if self.rollout_mode == "fixed_horizon":
+            with torch.no_grad():
+                for _ in range(num_batches):
+                    traj, last_v = self.batch_runner.collect_fixed(local_b, self.rollout_horizon)
+                    self.rollout_buffer.store_fixed_trajectory(traj, last_v, self.gamma, self.lambda_gae)
+                    lens = traj.finished_episode_lengths()
+                    total_episodes += int(lens.numel())
+                    ep_len.append(lens)
+                    ep_rew.append(traj.rewards.max(dim=0).values)  # largest single-step reward of every lane's rows
+            self._finish_collect(ep_rew, ep_len, total_episodes)
+            return
         with torch.no_grad():
             for _ in range(num_batches):
                 traj = self.batch_runner.collect(local_b)
-                self.rollout_buffer.store_trajectory(traj)
+                self.rollout_buffer.store_trajectory(traj, self.gamma, self.lambda_gae)
                 total_episodes += traj.B
                 # "episode reward" statistic of the reference: the largest single-step reward of the env's row
                 valid = traj.valid()
@@ -311,6 +336,10 @@ class PPOTrainer:
                 rmax = torch.where(frozen_zero, rmax.clamp_min(0.0), rmax)
                 ep_rew.append(rmax)
                 ep_len.append(torch.where(traj.ep_len > 0, traj.ep_len, torch.full_like(traj.ep_len, traj.T)))
+        self._finish_collect(ep_rew, ep_len, total_episodes)
+
+    def _finish_collect(self, ep_rew, ep_len, total_episodes: int) -> None:
+        """Episode statistics, the global timestep count and the rollout/* scalars of one collect_rollouts call."""
         ep_rew = torch.cat(ep_rew).cpu().numpy()
         ep_len = torch.cat(ep_len).cpu().numpy()
         self.episode_rewards.extend(ep_rew.tolist())
@@ -327,7 +356,8 @@ class PPOTrainer:
         if len(ep_rew):
             self.last_rollout_stats = {
                 "mean_max_episode_reward": float(np.mean(ep_rew)), "max_episode_reward": float(np.max(ep_rew)),
-                "mean_episode_length": float(np.mean(ep_len)), "timesteps": n_global}
+                "mean_episode_length": float(np.mean(ep_len)) if len(ep_len) else float("nan"), "timesteps": n_global,
+                "episodes": int(total_episodes) * self.world}
             for k in ("mean_max_episode_reward", "max_episode_reward", "mean_episode_length"):
                 self.writer.add_scalar(f"rollout/{k}", self.last_rollout_stats[k], self.total_timesteps)
 

@@ -71,8 +71,11 @@ class RolloutBuffer:
             self.buffer_size += n
 
     # ------------------------------------------------------------------ device interface
-    def store_trajectory(self, traj: Trajectory) -> int:
-        """Compact an engine trajectory into the buffer on the device; returns the number of kept steps."""
+    def store_trajectory(self, traj: Trajectory, gamma: float = None, lambda_gae: float = None) -> int:
+        """Compact an engine trajectory into the buffer on the device; returns the number of kept steps.
+        With ``gamma``/``lambda_gae`` the raw GAE advantages and returns are computed first, on the step-major [T][B] layout
+        where the scan is fully coalesced (``g2048_gae_tb``, one lane per env, bit-identical to the reference's scan over
+        the compacted buffer), and compacted along: PPODataset then skips its own scan."""
         if traj.log_probs is None or traj.values is None:
             raise ValueError("PPO needs log_probs and values; this trajectory has none (naive policy?)")
         dev = traj.ep_len.device
@@ -81,6 +84,11 @@ class RolloutBuffer:
         N = int(lens.sum().item())
         if N == 0:
             return 0
+        with_gae = gamma is not None and lambda_gae is not None
+        tr_adv = tr_ret = None
+        if with_gae:
+            tr_adv, tr_ret = torch.empty_like(traj.rewards), torch.empty_like(traj.rewards)
+            nv.gae_tb(traj.rewards, traj.values, traj.ep_len, tr_adv, tr_ret, traj.T, traj.B, gamma, lambda_gae)
         out = {
             "boards": torch.empty((N, 16), dtype=torch.uint8, device=dev),
             "actions": torch.empty(N, dtype=torch.uint8, device=dev),
@@ -90,9 +98,33 @@ class RolloutBuffer:
             "values": torch.empty(N, dtype=torch.float32, device=dev),
             "terms": torch.empty(N, dtype=torch.uint8, device=dev),
         }
+        if with_gae:
+            out["raw_advantages"] = torch.empty(N, dtype=torch.float32, device=dev)
+            out["raw_returns"] = torch.empty(N, dtype=torch.float32, device=dev)
         nv.compact(traj.boards, traj.meta, traj.rewards, traj.log_probs, traj.values, traj.ep_len, offsets,
                    out["boards"], out["actions"], out["masks"], out["rewards"], out["log_probs"], out["values"],
-                   out["terms"], traj.T, traj.B, N)
+                   out["terms"], traj.T, traj.B, N, tr_adv=tr_adv, tr_ret=tr_ret, out_adv=out.get("raw_advantages"),
+                   out_ret=out.get("raw_returns"))
+        self._segments.append(("device", out))
+        self.buffer_size += N
+        return N
+
+    def store_fixed_trajectory(self, traj, last_values: torch.Tensor, gamma: float, lambda_gae: float) -> int:
+        """A fixed-horizon trajectory (``FixedTrajectory``: all T x B rows are samples, ``terms`` marks the episode
+        boundaries): GAE on the [T][B] layout bootstrapped from ``last_values`` = V(state after the last step)
+        (``g2048_gae_tb_boot``), then the rows are taken over as they lie (step-major; copied, because the engine reuses
+        its trajectory workspace)."""
+        T, B = traj.T, traj.B
+        adv, ret = torch.empty_like(traj.rewards), torch.empty_like(traj.rewards)
+        nv.gae_tb_boot(traj.rewards, traj.values, traj.meta, last_values.to(torch.float32).reshape(-1).contiguous(), adv, ret,
+                       T, B, gamma, lambda_gae)
+        N = T * B
+        out = {
+            "boards": traj.boards.reshape(N, 16).clone(), "actions": (traj.meta & 3).reshape(N),
+            "masks": ((traj.meta >> 2) & 15).reshape(N), "rewards": traj.rewards.reshape(N).clone(),
+            "log_probs": traj.log_probs.reshape(N).clone(), "values": traj.values.reshape(N).clone(),
+            "terms": ((traj.meta >> 6) & 1).reshape(N), "raw_advantages": adv.reshape(N), "raw_returns": ret.reshape(N),
+        }
         self._segments.append(("device", out))
         self.buffer_size += N
         return N
@@ -107,7 +139,8 @@ class RolloutBuffer:
                 parts.append(_host_segment_to_device(seg, device))
         if not parts:
             raise ValueError("rollout buffer is empty")
-        return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+        keys = [k for k in parts[0] if all(k in p for p in parts)]  # raw GAE columns only if every segment carries them
+        return {k: (parts[0][k] if len(parts) == 1 else torch.cat([p[k] for p in parts])) for k in keys}
 
     def get_buffer_data(self):
         """The reference's dict of numpy arrays: observations f32 [N, *obs_dims] (one-hot), actions f32 [N, 4]

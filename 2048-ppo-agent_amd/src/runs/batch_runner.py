@@ -100,6 +100,24 @@ class BatchRunner:
                                                sync_every=getattr(fn, "sync_every", 8), **kw)
         return self._collect_host_callable(B, fn, fill_frozen)
 
+    def collect_fixed(self, batch_size: int, horizon: int, restart: bool = False):
+        """Throughput mode (the reference has only the lock-step loop of src/runs/batch_runner.py:117):
+        ``horizon`` lock-steps of ``batch_size`` always-live lanes with per-lane auto-reset, policy in the loop.
+        -> (FixedTrajectory, last_values f32 [B]) where last_values = V(state after the last step), the bootstrap of the
+        GAE scan.  Env state persists across calls.  Needs a TorchActionFunction-style ``act_fn`` (``policy_fn``)."""
+        if self._act_fn is None:
+            raise ValueError("The action function is not set.")
+        fn = self._act_fn
+        if not hasattr(fn, "policy_fn"):
+            raise ValueError("the fixed-horizon mode needs a policy act_fn (TorchActionFunction)")
+        if batch_size is None or int(batch_size) <= 0 or int(horizon) <= 0:
+            raise ValueError("batch_size and horizon must be positive integers")
+        traj = self._engine.rollout_policy_fixed(int(batch_size), int(horizon), fn.policy_fn, use_mask=fn.use_mask,
+                                                 sample=fn.sample_actions, B_total=self.total_envs, env0=self.env0,
+                                                 restart=restart)
+        _, last_values = fn.policy_fn(traj.final_boards, traj.final_masks)
+        return traj, last_values.to(torch.float32).reshape(-1)
+
     def _collect_host_callable(self, B: int, fn: Callable, fill_frozen: bool) -> Trajectory:
         """Arbitrary Python act_fn: env + key splits on the device, the callable per env on the host."""
         eng, mode, dev = self._engine, self.rng_mode, self.device

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 1
+#define G2048_ABI_VERSION 2
 #define G2048_EINVAL (-1)
 #define G2048_RNG_LEGACY 0
 #define G2048_RNG_PARTITIONABLE 1
@@ -112,6 +112,21 @@ int g2048_policy_step(uint32_t act_sub0, uint32_t act_sub1, uint32_t step_sub0, 
                       int64_t B_total, int64_t env0, int fill_frozen, int rng_mode, uint32_t *live_count,
                       void *stream);
 
+/* Fixed-horizon throughput mode (no reference counterpart; it replaces the lock-step `while not all terminated` of
+ * src/runs/batch_runner.py:117): g2048_policy_step for EVERY lane at every call, and a lane whose step
+ * terminates starts its next episode at once: state = env.init(split(fold_in(step_sub, 0xFFFFFFFF), B_total)[env0 + i]).
+ * Row t of the trajectory is written as by g2048_policy_step (done_after = 1 marks the episode boundary); boards/masks hold
+ * the state for step t+1 (a fresh board after a terminal step), ep_len[i] the steps of the running episode.  The key chain
+ * advances exactly as in the reference (two splits per lock-step), so until a lane's first termination its rows are those
+ * of the lock-step mode under the same policy outputs. */
+int g2048_policy_step_autoreset(uint32_t act_sub0, uint32_t act_sub1, uint32_t step_sub0, uint32_t step_sub1,
+                                const float *logits, const float *values, int use_mask, int sample, int64_t t,
+                                uint8_t *boards, uint8_t *masks, int32_t *ep_len, uint8_t *tr_boards, uint8_t *tr_meta,
+                                float *tr_rewards, float *tr_logp, float *tr_values, int64_t B, int64_t B_total,
+                                int64_t env0, int rng_mode, void *stream);
+/* (host, no device work) out[2] = jax.random.fold_in(step_sub, 0xFFFFFFFF): the per-step reset sub-key of that mode. */
+int g2048_reset_key(uint32_t step_sub0, uint32_t step_sub1, uint32_t *out /*host [2]*/);
+
 /* ---- rollout buffer + GAE ----------------------------------------------------------------------- */
 
 /* GAE over the step-major trajectory: env e uses steps 0..ep_len[e]-1 (its last kept step is terminal).
@@ -120,17 +135,25 @@ int g2048_policy_step(uint32_t act_sub0, uint32_t act_sub1, uint32_t step_sub0, 
 int g2048_gae_tb(const float *tr_rewards, const float *tr_values, const int32_t *ep_len, float *tr_adv,
                  float *tr_ret, int64_t T, int64_t B, double gamma, double lam, void *stream);
 
+/* GAE over a fixed-horizon trajectory: all T steps of every lane, episode boundaries = the done_after bit of tr_meta (the
+ * reset at `terminations[step]` of src/ppo/data_loader.py:103-130), bootstrapped from last_values[e] = V(state after step
+ * T-1) where the horizon cut an episode.  Same float32 operation order as g2048_gae_tb. */
+int g2048_gae_tb_boot(const float *tr_rewards, const float *tr_values, const uint8_t *tr_meta, const float *last_values,
+                      float *tr_adv, float *tr_ret, int64_t T, int64_t B, double gamma, double lam, void *stream);
+
 /* GAE over a flat buffer with termination flags (the reference's layout, data_loader.py:103-130). */
 int g2048_gae_flat(const float *rewards, const float *values, const uint8_t *terms, float *adv, float *ret,
                    int64_t N, double gamma, double lam, void *stream);
 
 /* RolloutBuffer.store_batch (src/ppo/rollout_buffer.py:164-187): keep steps 0..ep_len[e]-1 of every env,
- * env-major, at offsets[e] (exclusive prefix sum of ep_len, int64).  f32 outputs may be NULL with their
- * inputs.  out_terms[n] = 1 on each env's last kept step. */
-int g2048_compact(const uint8_t *tr_boards, const uint8_t *tr_meta, const float *tr_rewards,
-                  const float *tr_logp, const float *tr_values, const int32_t *ep_len, const int64_t *offsets,
-                  uint8_t *out_boards, uint8_t *out_actions, uint8_t *out_masks, float *out_rewards,
-                  float *out_logp, float *out_values, uint8_t *out_terms, int64_t T, int64_t B, void *stream);
+ * env-major, at offsets[e] (exclusive prefix sum of ep_len, int64).  The optional f32 columns (log-probs, values, and
+ * the advantages / returns of g2048_gae_tb computed on the coalesced [T][B] layout) may be NULL together with their
+ * outputs.  out_terms[n] = 1 on each env's last kept step. */
+int g2048_compact(const uint8_t *tr_boards, const uint8_t *tr_meta, const float *tr_rewards, const float *tr_logp,
+                  const float *tr_values, const float *tr_adv, const float *tr_ret, const int32_t *ep_len,
+                  const int64_t *offsets, uint8_t *out_boards, uint8_t *out_actions, uint8_t *out_masks, float *out_rewards,
+                  float *out_logp, float *out_values, float *out_adv, float *out_ret, uint8_t *out_terms, int64_t T,
+                  int64_t B, void *stream);
 
 /* ---- policy network (inference) ------------------------------------------------------------------- */
 

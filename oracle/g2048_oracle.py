@@ -371,6 +371,60 @@ class Runner:
         return out
 
 
+def fold_in(k: np.ndarray, data: int) -> np.ndarray:
+    """jax.random.fold_in(key, data) for 32-bit data: one threefry block over the counter words (0, data)."""
+    a, b = threefry2x32(np.uint32(k[0]), np.uint32(k[1]), np.uint32(0), np.uint32(data))
+    return np.array([a, b], dtype=np.uint32)
+
+
+class AutoResetRunner(Runner):
+    """Fixed-horizon rollout with per-lane auto-reset: the throughput mode of the build.  There is no
+    reference code for it (the reference only has the lock-step loop, src/runs/batch_runner.py:117); this restatement
+    defines it in terms of the pinned primitives: the BatchRunner key chain (one init split, then act / step splits per
+    lock-step), ``env_step`` for every lane at every step, and for a lane whose step terminated
+    ``env_init(split(fold_in(step_sub, 0xFFFFFFFF), B)[e])`` as its state for the next step.  Env state and the key chain
+    persist across ``run`` calls."""
+
+    def __init__(self, seed: int, mode: int):
+        super().__init__(seed, mode)
+        self.state = None
+
+    def run(self, B: int, T: int, policy_fn=None, actions=None):
+        """T steps.  Either ``policy_fn(act_keys, boards, masks) -> (a, lp, v)`` or recorded ``actions`` [T, B].
+        Returns step-major arrays [T, B]: boards/masks BEFORE step t, rewards/terms AFTER it, + final_boards/final_masks."""
+        mode = self.mode
+        if self.state is None:
+            boards = env_init(split(self._next_sub(), B, mode), mode)
+            self.state = (boards, legal_mask(boards))
+        boards, masks = self.state
+        tr = {k: [] for k in ("boards", "actions", "masks", "log_probs", "values", "rewards", "terms")}
+        alive = np.zeros(B, dtype=bool)  # "done" input of env_step: every lane is live at every step
+        for t in range(T):
+            act_keys = split(self._next_sub(), B, mode)
+            if actions is not None:
+                a, lp, v = np.asarray(actions[t], np.int32), np.zeros(B, np.float32), np.zeros(B, np.float32)
+            else:
+                a, lp, v = policy_fn(act_keys, boards, masks)
+            step_sub = self._next_sub()
+            nb, r, nm, nd = env_step(boards, masks, alive, a, split(step_sub, B, mode), mode)
+            tr["boards"].append(boards)
+            tr["actions"].append(np.asarray(a, np.int32))
+            tr["masks"].append(masks)
+            tr["log_probs"].append(np.asarray(lp, np.float32))
+            tr["values"].append(np.asarray(v, np.float32))
+            tr["rewards"].append(r)
+            tr["terms"].append(nd)
+            if nd.any():
+                fresh = env_init(split(fold_in(step_sub, 0xFFFFFFFF), B, mode), mode)
+                nb = np.where(nd[:, None], fresh, nb)
+                nm = np.where(nd[:, None], legal_mask(fresh), nm)
+            boards, masks = nb, nm
+        self.state = (boards, masks)
+        out = {k: np.stack(v, axis=0) for k, v in tr.items()}
+        out["final_boards"], out["final_masks"] = boards, masks
+        return out
+
+
 # --------------------------------------------------------------------------------------
 # rollout buffer compaction + GAE
 # --------------------------------------------------------------------------------------
@@ -405,6 +459,29 @@ def gae(rewards, values, terms, gamma: float, lam: float):
         adv[i] = last_gae
         ret[i] = np.float32(last_gae + v[i])
         last_v = v[i]
+    return adv, ret
+
+
+def gae_bootstrap(rewards, values, terms, last_values, gamma: float, lam: float):
+    """The same scan per lane over step-major [T, B] arrays of a fixed-horizon rollout, started from
+    last_values[e] = V(state after step T-1) (the reference's loop with last_value initialised to the bootstrap)."""
+    r = np.asarray(rewards, np.float32)
+    v = np.asarray(values, np.float32)
+    d = np.asarray(terms, bool)
+    T, B = r.shape
+    adv, ret = np.zeros_like(r), np.zeros_like(r)
+    g, gl = np.float32(gamma), np.float32(gamma * lam)
+    for e in range(B):
+        last_gae, last_v = np.float32(0.0), np.float32(last_values[e])
+        for t in range(T - 1, -1, -1):
+            if d[t, e]:
+                last_v = np.float32(0.0)
+                last_gae = np.float32(0.0)
+            delta = np.float32(np.float32(r[t, e] + np.float32(g * last_v)) - v[t, e])
+            last_gae = np.float32(delta + np.float32(gl * last_gae))
+            adv[t, e] = last_gae
+            ret[t, e] = np.float32(last_gae + v[t, e])
+            last_v = v[t, e]
     return adv, ret
 
 

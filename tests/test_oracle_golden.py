@@ -115,3 +115,39 @@ def test_compaction_oracle_matches_reference_rollout_buffer():
     assert (npo.compact(ref["buffer/in_rew"], lens) == ref["buffer/out_rewards"]).all()
     assert (npo.compact(ref["buffer/in_term"], lens) == ref["buffer/out_terminations"]).all()
     assert (npo.compact(ref["buffer/in_obs"], lens).reshape(20, 16, 31) == ref["buffer/out_observations"]).all()
+
+
+@pytest.mark.parametrize("mode", [npo.MODE_LEGACY, npo.MODE_PARTITIONABLE])
+def test_autoreset_oracle_is_pinned_on_the_lockstep_oracle(mode):
+    """The fixed-horizon / auto-reset restatement has no reference artifact of its own; it is pinned on the lock-step
+    oracle (which the reference's assets pin): under the same policy every lane's FIRST episode is row for row the
+    lock-step episode, and a restarted lane begins on a two-tile board."""
+    B = 8
+
+    def pf(keys, boards, masks):
+        a, lp = npo.act_randomly(keys, masks, mode)
+        return a, lp, np.zeros(len(a), np.float32)
+
+    ref = npo.Runner(3, mode).run(B, "random")
+    T = ref["actions"].shape[1] + 60
+    ar = npo.AutoResetRunner(3, mode).run(B, T, policy_fn=pf)
+    lens = npo.episode_lengths(ref["terms"])
+    for e in range(B):
+        n = lens[e]
+        assert (ar["boards"][:n, e] == ref["boards"][e, :n]).all() and (ar["actions"][:n, e] == ref["actions"][e, :n]).all()
+        assert (ar["rewards"][:n, e] == ref["rewards"][e, :n]).all() and ar["terms"][n - 1, e] and not ar["terms"][:n - 1, e].any()
+        if n < T:
+            assert (ar["boards"][n, e] > 0).sum() == 2 and ar["boards"][n, e].max() <= 2
+    assert ar["terms"].sum() > B  # lanes kept playing after their first episode
+
+
+def test_bootstrapped_gae_restatement_reduces_to_the_reference_scan():
+    rng = np.random.default_rng(0)
+    T, B = 40, 6
+    r, v = rng.standard_normal((T, B)).astype(np.float32), rng.standard_normal((T, B)).astype(np.float32)
+    d = rng.random((T, B)) < 0.1
+    d[-1] = True  # every lane ends on a terminal step: the bootstrap value cannot matter
+    adv, ret = npo.gae_bootstrap(r, v, d, rng.standard_normal(B).astype(np.float32), 0.99, 0.95)
+    for e in range(B):
+        fa, fr = npo.gae(r[:, e], v[:, e], d[:, e], 0.99, 0.95)
+        assert (adv[:, e] == fa).all() and (ret[:, e] == fr).all()
