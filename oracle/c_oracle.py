@@ -134,3 +134,8 @@ def gae(r, v, term, gamma, lam):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n: int):
+    """OpenMP threads used by the batched entry points from now on (bench.py's cpu_baseline matrix)."""
+    lib().orc_set_num_threads(C.c_int(int(n)))

@@ -388,6 +388,10 @@ void orc_gae(const float *r, const float *v, const uint8_t *term, float *adv, fl
     }
 }
 
+void orc_set_num_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

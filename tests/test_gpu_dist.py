@@ -60,6 +60,85 @@ def _worker(rank, world, port, results):
         dist.destroy_process_group()
 
 
+def _worker_default_shape(rank, world, port, results):
+    """Default model shape (d 256, 8 heads, ff 1024; 2 layers to keep it quick): the HIP update kernels and the captured
+    graph with the flat all-reduce bucket under world > 1.  Checks: the graph stays on, parameters identical across ranks,
+    and the all-reduced sharded gradient == the single-process gradient of the full batch."""
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, os.path.join(root, "2048-ppo-agent_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from src.ppo import PPOAgent, PPOTrainer, RolloutBuffer
+        from src.ppo.data_loader import DeviceBatches, PPODataset
+        from src.runs import BatchRunner
+
+        dev = torch.device("cuda:0")
+        torch.manual_seed(2000 + rank)
+        agent = PPOAgent(hidden_dim=512, d_model=256, nhead=8, num_layers=2, dim_feedforward=1024, dropout=0.0, reduction="cls")
+        optim = dict(opt_name="adamw", max_lr=4e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,
+                     warmup_steps_ratio=0.025, scheduler_names=["constant", "constant"],
+                     blacklist_weight_modules=["norm", "embedding"])
+        tr = PPOTrainer(agent, BatchRunner(init_seed=0, device=dev), RolloutBuffer(31, 16, 4), optim, max_steps=100,
+                        use_action_mask=True, device=dev, mixed_precision="bfloat16", target_kl=0.25, rollout_amp=True,
+                        max_samples_per_epoch=4 * 1024, shuffle_on_reset=True, log_dir=f"/tmp/g2048_dist2_{rank}")
+        assert tr.use_hip_graph and tr._flat_grad is not None
+        tr.collect_rollouts(128, 1)  # 64 envs per rank
+        # (1) sharded gradient through the graph == full-batch gradient in one process.  Every rank gathers the SAME 2 x M
+        # samples; rank r back-propagates its half, the bucket is all-reduced; rank 0 also runs the full batch eagerly.
+        M = 512
+        data = tr.rollout_buffer.device_data(dev)
+        cols = {k: data[k][:2 * M].contiguous() for k in ("boards", "actions", "masks", "log_probs", "raw_advantages", "raw_returns")}
+        gathered = {}
+        for k, v in cols.items():  # rank 0's samples for everyone (the ranks hold different envs)
+            lst = [torch.zeros_like(v.cpu()) for _ in range(world)]
+            dist.all_gather(lst, v.cpu())
+            gathered[k] = lst[0].to(dev)
+        sample = lambda sl: dict(obs=gathered["boards"][sl], actions=gathered["actions"][sl], masks=gathered["masks"][sl],
+                                 old_lp=gathered["log_probs"][sl], adv=gathered["raw_advantages"][sl].clamp(-3, 3),
+                                 ret=gathered["raw_returns"][sl].clamp(-3, 3))
+        agent.train()
+        mine = sample(slice(rank * M, (rank + 1) * M))
+        from src.ppo.ppo_trainer import _GraphedFwdBwd
+
+        gr = _GraphedFwdBwd(tr, M, {k: v.contiguous() for k, v in mine.items()})
+        gr.run({k: v.contiguous() for k, v in mine.items()})
+        tr._allreduce_grads()
+        got = tr._flat_grad.clone()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(tr._params, tr._flat_views)), "grads must live in the bucket"
+        # the single-process answer: the mean of the two half-batch gradients (equal halves -> the full-batch mean loss)
+        want = torch.zeros_like(got)
+        for r in range(world):
+            tr._zero_grad()
+            tr._loss_backward(**{k: v.contiguous() for k, v in sample(slice(r * M, (r + 1) * M)).items()})
+            want += torch.cat([p.grad.flatten() for p in tr._params]) / world
+        tr._bind_flat_grads()
+        rel = ((got - want).norm() / want.norm()).item()
+        assert rel < 2e-3, rel
+        # (2) a real update at this shape: graph replayed, parameters stay identical across ranks
+        tr._graphs.clear()
+        m = tr.update_policy(batch_size=1024, n_epochs=1)
+        assert m["n_updates"] >= 1 and m["hip_graph"] is True and tr.hip_graph_fallback is None
+        flat = torch.cat([p.detach().flatten() for p in agent.parameters()]).cpu()
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]) and torch.isfinite(flat).all()
+        results[rank] = (m["n_updates"], rel)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_default_shape_graph_and_gradient(dev):
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_worker_default_shape, args=(world, port, results), nprocs=world, join=True)
+        r = dict(results)
+        assert set(r) == {0, 1} and r[0][0] == r[1][0]
+
+
 def test_two_ranks_on_one_gpu(dev):
     world, port = 2, _free_port()
     with mp.Manager() as mgr:

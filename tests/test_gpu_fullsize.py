@@ -38,6 +38,21 @@ def test_shard_of_524288_boards_matches_oracle_slice(dev):
     assert (tr.final_boards.cpu().numpy() == ref["final_boards"]).all()
 
 
+def test_shard_of_1M_boards_matches_oracle_slice(dev):
+    """configs[4]: 1 048 576 envs over 8 GPUs -- rank 3's 131 072-board slice equals that slice of the single-device batch
+    (keys come from the GLOBAL split, so a shard never depends on how many ranks there are)."""
+    B_total, per = 1 << 20, 1 << 17
+    r = BatchRunner(init_seed=42, act_fn=act_drul, rng_mode="partitionable", device=dev, env0=3 * per, total_envs=B_total)
+    tr = r.collect(per)
+    ref = orc.rollout(npo.key(42), B_total, 3 * per, per, 0, 1)
+    assert (tr.ep_len.cpu().numpy() == ref["ep_len"]).all()
+    assert (tr.final_boards.cpu().numpy() == ref["final_boards"]).all()
+    # the same slice computed as two half-shards (16 ranks) is the same again
+    halves = [BatchRunner(init_seed=42, act_fn=act_drul, rng_mode="partitionable", device=dev, env0=3 * per + h * per // 2,
+                          total_envs=B_total).collect(per // 2) for h in (0, 1)]
+    assert torch.equal(torch.cat([h.final_boards for h in halves]), tr.final_boards)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_step_properties_at_4M_boards(dev, mode):
     """2^22 boards through g2048_step (explicit keys): sum of tile values grows by exactly the spawned tile, rewards

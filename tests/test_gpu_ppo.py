@@ -127,6 +127,32 @@ def test_collect_update_smoke(dev, kind, tmp_path, monkeypatch):
         tr2.load_checkpoint("bad.pt")
 
 
+def test_mlp_policy_full_loop_at_4096_envs(dev, tmp_path, monkeypatch):
+    """BASELINE.json configs[1]: 4 096 parallel envs, MLP policy, full PPO loop with the reference's trainer config
+    (5 epochs, minibatch 2048, 300 k samples per epoch, bf16): two iterations learn something measurable and every
+    episode of the rollout is a complete one."""
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    agent = MLPAgent(hidden_dim=512, trunk_dim=512)
+    tr = PPOTrainer(agent, BatchRunner(init_seed=0, device=dev), RolloutBuffer(31, 16, 4), OPTIM, max_steps=500000, device=dev,
+                    gamma=0.99, lambda_gae=0.95, clip_epsilon=0.2, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5,
+                    target_kl=0.25, use_action_mask=True, mixed_precision="bfloat16", max_samples_per_epoch=300000,
+                    shuffle_on_reset=True, rollout_amp=True)
+    lengths = []
+    for _ in range(2):
+        tr.collect_rollouts(4096, 1)
+        n = tr.rollout_buffer.buffer_size
+        data = tr.rollout_buffer.device_data(dev)
+        assert int(data["terms"].sum()) == 4096 and n == tr.last_rollout_stats["timesteps"]  # 4 096 complete episodes
+        assert (data["rewards"] >= 0).all()  # masked policy: no illegal move
+        m = tr.update_policy(batch_size=2048, n_epochs=5)
+        assert m["n_updates"] == 5 * (min(n, 300000) // 2048) and np.isfinite(m["total_loss"])
+        assert m["hip_graph"] is True
+        lengths.append(tr.last_rollout_stats["mean_episode_length"])
+    assert len(tr.episode_lengths) == 8192 and lengths[0] > 50
+    assert all(torch.isfinite(p).all() for p in agent.parameters())
+
+
 def test_train_loop_and_resume_modes(dev, tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     torch.manual_seed(0)
