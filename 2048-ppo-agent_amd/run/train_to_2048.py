@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: train the Transformer policy until a 2048 tile shows up; report the wall-clock to the first
+2048 tile and the 1000-episode max-tile histogram next to the reference's published baselines.
+
+    python 2048-ppo-agent_amd/run/train_to_2048.py --envs 65536 --minutes 15 --out result.json
+    (N GPUs: python -m torch.distributed.run --nproc-per-node N ... train_to_2048.py --envs 1048576)
+
+Protocol.  Training = the reference's loop (collect_rollouts -> update_policy, configs/trainer/default.yaml, model
+configs/model/transformer_combined.yaml) on ``--envs`` parallel boards (global, sharded by index over the ranks).  After
+every iteration the largest tile that occurred on any board of the rollout is read back; "first 2048" is the wall-clock
+(training only, evaluation time excluded) of the first iteration whose rollout contains one.  Evaluation = the reference's
+histogram protocol (run/viz_ppo_agent.py:267-289): 1000 episodes, seed 42, 10 batches x 100 envs, greedy policy with the
+legal-action mask, metric = largest tile of the final board.  Published baselines (reference README): random 109.17, DRUL
+189.44, the reference's trained PPO agent about 383 (2048 never reached).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from src.ppo import PPOAgent, PPOTrainer, RolloutBuffer  # noqa: E402
+from src.runs import BatchRunner, evaluate_agent  # noqa: E402
+
+TRAINER = dict(gamma=0.99, lambda_gae=0.95, clip_epsilon=0.2, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5,
+               target_kl=0.25, use_action_mask=True, mixed_precision="bfloat16", max_samples_per_epoch=300000,
+               shuffle_on_reset=True)
+OPTIM = dict(opt_name="adamw", max_lr=4e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, warmup_steps_ratio=0.025,
+             scheduler_names=["constant", "constant"], blacklist_weight_modules=["norm", "embedding"])
+MODEL = dict(observation_dim=31, action_dim=4, hidden_dim=512, d_model=256, nhead=8, num_layers=4, dim_feedforward=1024,
+             dropout=0.1, reduction="cls")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=65536, help="parallel boards (global)")
+    ap.add_argument("--minutes", type=float, default=15.0, help="training budget (wall-clock, evaluation excluded)")
+    ap.add_argument("--evals", type=int, default=3, help="intermediate evaluations (plus untrained and final)")
+    ap.add_argument("--mode", default="episodes", choices=["episodes", "fixed_horizon"])
+    ap.add_argument("--horizon", type=int, default=128)
+    ap.add_argument("--stop-at-2048", action="store_true", help="stop training at the first 2048 tile")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    torch.manual_seed(0)
+    agent = PPOAgent(**MODEL)
+    tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), OPTIM, max_steps=500000, device=dev,
+                    rollout_amp=True, log_dir="/tmp/g2048_train_to_2048", rollout_mode=a.mode, rollout_horizon=a.horizon,
+                    **TRAINER)
+
+    def evaluate(minutes):
+        ev = evaluate_agent(agent, dev, 1000) if rank == 0 else None
+        if world > 1:
+            dist.barrier()
+        if ev is not None:
+            ev.update(train_minutes=round(minutes, 2), timesteps=tr.total_timesteps)
+            print(f"eval @ {minutes:.2f} min / {tr.total_timesteps} steps: mean max tile {ev['mean_max_tile']:.1f}  {ev['percent']}",
+                  flush=True)
+        return ev
+
+    evals = [evaluate(0.0)]
+    train_s, it, first_2048, log = 0.0, 0, None, []
+    next_eval = a.minutes / (a.evals + 1)
+    while train_s / 60 < a.minutes:
+        it += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.collect_rollouts(a.envs, 1)
+        # the largest exponent on any board the rollout visited (the trajectory rows are still in the buffer)
+        top = int(tr.rollout_buffer.device_data(dev)["boards"].max().item())
+        if world > 1:
+            t = torch.tensor([top], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            top = int(t.item())
+        m = tr.update_policy(batch_size=2048, n_epochs=5)
+        torch.cuda.synchronize()
+        train_s += time.perf_counter() - t0
+        st = tr.last_rollout_stats
+        log.append({"iteration": it, "train_minutes": round(train_s / 60, 3), "timesteps": tr.total_timesteps,
+                    "max_tile_in_rollout": 1 << top, "mean_episode_length": round(st["mean_episode_length"], 1),
+                    "kl": round(m["kl_divergence"], 4), "n_updates": m["n_updates"], "hip_graph": m.get("hip_graph")})
+        if rank == 0:
+            print(json.dumps(log[-1]), flush=True)
+        if top >= 11 and first_2048 is None:
+            first_2048 = {"train_minutes": round(train_s / 60, 3), "iteration": it, "timesteps": tr.total_timesteps}
+            if rank == 0:
+                print("FIRST 2048 TILE:", first_2048, flush=True)
+            if a.stop_at_2048:
+                break
+        if train_s / 60 >= next_eval and train_s / 60 < a.minutes:
+            evals.append(evaluate(train_s / 60))
+            next_eval += a.minutes / (a.evals + 1)
+    evals.append(evaluate(train_s / 60))
+    if rank == 0:
+        res = {"config": "BASELINE.json configs[4] protocol" + ("" if world * 131072 == a.envs else
+                         f" at {a.envs} envs on {world} GPU(s) (the 1 M-env / 8-GPU size needs an 8-GPU node)"),
+               "envs": a.envs, "n_gpus": world, "rollout_mode": a.mode, "train_minutes": round(train_s / 60, 2),
+               "timesteps": tr.total_timesteps, "env_steps_per_sec_training": round(tr.total_timesteps / max(train_s, 1e-9), 1),
+               "first_2048_tile": first_2048, "evals": evals, "iterations": log,
+               "baselines_mean_max_tile": {"random": 109.17, "drul": 189.44, "reference_ppo_readme": 383}}
+        print(json.dumps({k: v for k, v in res.items() if k != "iterations"}))
+        if a.out:
+            os.makedirs(os.path.dirname(os.path.abspath(a.out)) or ".", exist_ok=True)
+            json.dump(res, open(a.out, "w"), indent=1)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
