@@ -67,6 +67,8 @@ SIGNATURES = {
     "g2048_relu_dropout_fwd": [_vp, _vp, _i64, _i32, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_relu_dropout_bwd_workspace_floats": [_i64, _i32],
     "g2048_relu_dropout_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, C.c_float, _vp],
+    "g2048_opt_workspace_floats": [_i32],
+    "g2048_opt_step": [_vp, _i32, _vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _i32, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp, _vp],
 }
 
 _lib = None
@@ -441,6 +443,57 @@ def embed_bwd(boards, dx0, dwt_dcls, p_drop: float = 0.0, seed: int = 0, seed_st
     _check(load().g2048_embed_bwd(_dev(boards, u8, 16 * M, "boards"), _dev(dx0, f32, M * 17 * 256, "dx0"),
                                   _dev(dwt_dcls, f32, 32 * 256, "dwt_dcls"), ws.data_ptr(), M, float(p_drop), int(seed),
                                   seed_state or None, _stream()), "g2048_embed_bwd")
+
+
+OPT_CHUNK = 2048  # G2048_OPT_CHUNK
+OPT_MAX_GROUPS = 4  # G2048_OPT_MAX_GROUPS
+
+
+class OptChunk(C.Structure):  # g2048_opt_chunk
+    _fields_ = [("param", _vp), ("offset", _i64), ("n", C.c_int32), ("group", C.c_int32)]
+
+
+class OptGroup(C.Structure):  # g2048_opt_group
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+
+
+def opt_chunk_table(params, offsets, groups, device) -> torch.Tensor:
+    """The device-resident chunk table of g2048_opt_step (u8 tensor holding g2048_opt_chunk records): parameter i (a
+    contiguous f32 device tensor) has its gradient/moments at element offsets[i] of the flat buffers and belongs to
+    hyper-parameter group groups[i]."""
+    recs = []
+    for p, off, grp in zip(params, offsets, groups):
+        if not p.is_cuda or p.dtype != f32 or not p.is_contiguous() or p.data_ptr() % 16 or off % 4:
+            raise NativeError(f"opt_chunk_table: parameter {tuple(p.shape)} {p.dtype} on {p.device} (offset {off}) is not a "
+                              "contiguous 16-byte aligned f32 device tensor at a flat offset that is a multiple of 4")
+        n = p.numel()
+        for c0 in range(0, n, OPT_CHUNK):
+            recs.append(OptChunk(p.data_ptr() + 4 * c0, off + c0, min(OPT_CHUNK, n - c0), grp))
+    arr = (OptChunk * len(recs))(*recs)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=u8)
+    return host.to(device)
+
+
+def opt_workspace(n_chunks: int, device) -> torch.Tensor:
+    """Zeroed workspace for g2048_opt_step (partials + the completion counter the kernel keeps at zero)."""
+    return torch.zeros(load().g2048_opt_workspace_floats(n_chunks), dtype=f32, device=device)
+
+
+def opt_step(table, n_chunks: int, grads, exp_avg, exp_avg_sq, groups, max_grad_norm: float, steps, scale, growth_tracker,
+             growth: float, backoff: float, growth_interval: int, workspace, info=None):
+    """Clip + AdamW (+ GradScaler unscale / skip / update when ``scale`` is given) for every chunk of ``table``; ``groups``:
+    list of (lr, beta1, beta2, eps, weight_decay)."""
+    if len(groups) > OPT_MAX_GROUPS:
+        raise NativeError(f"opt_step: {len(groups)} parameter groups, at most {OPT_MAX_GROUPS} are supported")
+    g = (OptGroup * len(groups))(*[OptGroup(*map(float, t)) for t in groups])
+    n = grads.numel()
+    _check(load().g2048_opt_step(
+        table.data_ptr(), n_chunks, _dev(grads, f32, None, "grads"), _dev(exp_avg, f32, n, "exp_avg"),
+        _dev(exp_avg_sq, f32, n, "exp_avg_sq"), C.cast(g, _vp), len(groups), float(max_grad_norm if max_grad_norm else 0.0),
+        _dev(steps, f32, 1, "steps"), steps.numel(), _dev(scale, f32, 1, "scale", optional=True),
+        _dev(growth_tracker, torch.int32, 1, "growth_tracker", optional=True), float(growth), float(backoff),
+        int(growth_interval), _dev(workspace, f32, None, "workspace"), _dev(info, f32, 2, "info", optional=True), _stream()),
+        "g2048_opt_step")
 
 
 def gather_minibatch(idx, boards, actions, masks, logp, adv, ret, out=None):

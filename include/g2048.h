@@ -290,6 +290,35 @@ int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, fl
 
 /* ---- PPO update: minibatch assembly ------------------------------------------------------------------------ */
 
+/* ---- optimiser step (update) ---------------------------------------------------------------------------- */
+
+/* One optimiser step for every parameter of the agent in two launches: GradScaler unscale + inf check, gradient-norm
+ * clipping, AdamW, GradScaler update (reference: src/ppo/ppo_trainer.py:413-434 = scaler.unscale_(opt);
+ * clip_grad_norm_(params, max_grad_norm); scaler.step(opt); scaler.update(), with opt = torch.optim.AdamW built by
+ * src/optim/configure_optimizers.py:16-127).
+ * grads / exp_avg / exp_avg_sq: flat f32 device buffers (16-byte aligned) sharing one element layout; chunks[n_chunks]
+ * (device memory): piece `n` <= G2048_OPT_CHUNK elements of one parameter tensor starting at `param` (16-byte aligned),
+ * whose gradient and moments start at element `offset` (a multiple of 4) of the flat buffers, hyper-parameters
+ * groups[group].  groups: host array, read during the call (the LR schedule changes lr every step).
+ * max_grad_norm <= 0: no clipping.  steps: device f32 [n_steps], the number of steps taken so far, one copy per parameter
+ * tensor as torch.optim keeps them (all equal; every entry +1 per non-skipped call).
+ * scale / growth_tracker: the GradScaler's device scalars, or NULL/NULL when no scaler is used (then gradients are taken
+ * as they are and nothing is skipped); with a scaler, a step whose gradients hold an inf/nan changes neither parameters
+ * nor moments nor steps, and the scale is multiplied by backoff; after growth_interval consecutive clean steps by growth.
+ * workspace: g2048_opt_workspace_floats(n_chunks) floats whose LAST 4 words the caller zeroed once (a completion
+ * counter the kernel leaves at zero).  info (optional, device f32[2]): total gradient norm before clipping, found_inf.
+ * Arithmetic is torch's fused AdamW (bias corrections in f64 from the step count); the summation order of the norm is
+ * fixed by the chunk table. */
+#define G2048_OPT_CHUNK 2048
+#define G2048_OPT_MAX_GROUPS 4
+typedef struct { float *param; int64_t offset; int32_t n; int32_t group; } g2048_opt_chunk;
+typedef struct { float lr, beta1, beta2, eps, weight_decay; } g2048_opt_group;
+int64_t g2048_opt_workspace_floats(int n_chunks);
+int g2048_opt_step(const g2048_opt_chunk *chunks, int n_chunks, const float *grads, float *exp_avg, float *exp_avg_sq,
+                   const g2048_opt_group *groups, int n_groups, float max_grad_norm, float *steps, int n_steps, float *scale,
+                   int32_t *growth_tracker, float growth, float backoff, int growth_interval, float *workspace,
+                   float *info, void *stream);
+
 /* Row i of the minibatch = sample idx[i] (int64, clamped to [0, N)) of the device-resident rollout buffer: boards
  * u8 [N][16], actions u8 [N], masks u8 [N], logp / adv / ret f32 [N] -> the o_* arrays of M rows.  One launch for what
  * the reference's DataLoader collation does per field (PPODataset.__getitem__, src/ppo/data_loader.py). */
