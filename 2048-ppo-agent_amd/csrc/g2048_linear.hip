@@ -13,12 +13,30 @@
 //   * epilogue: lanes l and l+32 exchange half their accumulators (v_permlane32_swap) so that every lane owns 64
 //     consecutive outputs of its token = 128 contiguous bytes, adds the bias and stores bf16.
 // The same kernel computes dX = dY . W with the transposed weight W^T[K][N] as its "weight".
+// Two fused epilogues for the feed-forward block of the encoder layer (K <= 256 kernel only):
+//   EPI_RELU_DROPOUT  y = dropout(relu(x W1^T + b1)) - linear1 forward without the bf16 round trip of the pre-activation;
+//   EPI_MASK_COLSUM   dz = (dy W2) / keep where the saved activation is non-zero, else 0, plus the column sums of dz
+//                     (= linear1's bias gradient): the input gradient of linear2 fused with the backward of
+//                     relu + dropout (replaces g2048_relu_dropout_bwd's pass over two [T][1024] matrices).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/g2048.h"
+#include "g2048_colsum_final.h"
 
 namespace {
+
+enum { EPI_NONE = 0, EPI_RELU_DROPOUT = 1, EPI_MASK_COLSUM = 2 };
+struct Epi {
+    float inv_keep;                 // 1 / (1 - p_drop)
+    uint32_t thr16, s0, s1;         // EPI_RELU_DROPOUT: keep threshold on 16 hash bits, seed words
+    const uint64_t *seed_state;     // optional device-resident word mixed into the seed (hipGraph replays)
+    int64_t row_elems;              // elements per output row in the dropout index (= N)
+    const uint16_t *mask;           // EPI_MASK_COLSUM: saved activation bf16 [T][ldm]
+    int64_t ldm;
+    float *partial;                 // [gridDim.x][N] column sums of this workgroup's tiles
+    int N;
+};
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -50,20 +68,53 @@ __device__ __forceinline__ void dma_chunk(char *dst, const __bf16 *w_slice, int6
 // group g of 8.  Pack to bf16, then exchange between lane halves (v_permlane32_swap: lanes 32-63 of the first operand
 // swap with lanes 0-31 of the second) so that the lower half owns the even groups and the upper half the odd ones,
 // 8 consecutive outputs = one 16-byte store each.  Executed by all 64 lanes (the swap needs EXEC all ones).
-template <bool HAS_BIAS>
-__device__ __forceinline__ void store_tile(f32x16 acc[4], const float *__restrict__ bias, __bf16 *yrow, int n0, int h, bool valid) {
+template <bool HAS_BIAS, int EPI>
+__device__ __forceinline__ void store_tile(f32x16 acc[4], const float *__restrict__ bias, __bf16 *yrow, int n0, int h, bool valid,
+                                           const Epi &E, int64_t tok, float *colacc) {
+    uint4 mk[8];
+    if (EPI == EPI_MASK_COLSUM) {  // the saved activations of this lane's 64 outputs, in the layout of the stores below
+        const uint16_t *mrow = E.mask + tok * E.ldm + n0 + 8 * h;
+        for (int q = 0; q < 8; ++q) mk[q] = *reinterpret_cast<const uint4 *>(mrow + 32 * (q >> 1) + 16 * (q & 1));
+    }
     for (int j = 0; j < 4; ++j) {
         if (HAS_BIAS)
             for (int g = 0; g < 4; ++g) {
                 const float4 bv = *reinterpret_cast<const float4 *>(bias + n0 + 32 * j + 8 * g + 4 * h);
                 acc[j][4 * g + 0] += bv.x; acc[j][4 * g + 1] += bv.y; acc[j][4 * g + 2] += bv.z; acc[j][4 * g + 3] += bv.w;
             }
+        if (EPI == EPI_RELU_DROPOUT) {
+            for (int i = 0; i < 16; i += 2) {
+                float a = fmaxf(acc[j][i], 0.f), b = fmaxf(acc[j][i + 1], 0.f);
+                if (E.thr16) {  // one 32-bit hash per pair of neighbouring columns, 16 bits each
+                    const uint64_t pair = (uint64_t)(tok * E.row_elems + n0 + 32 * j + (i & 3) + 8 * (i >> 2) + 4 * h) >> 1;
+                    uint32_t x = (uint32_t)pair * 0x9E3779B1u ^ E.s0;
+                    x ^= (uint32_t)(pair >> 32) * 0x85EBCA77u + E.s1;
+                    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+                    a = (x & 0xFFFFu) >= E.thr16 ? a * E.inv_keep : 0.f;
+                    b = (x >> 16) >= E.thr16 ? b * E.inv_keep : 0.f;
+                }
+                acc[j][i] = a; acc[j][i + 1] = b;
+            }
+        }
+        if (EPI == EPI_MASK_COLSUM)
+            for (int i = 0; i < 16; ++i) acc[j][i] *= E.inv_keep;
         for (int m = 0; m < 2; ++m) {
             uint32_t ax = pack2(acc[j][8 * m + 0], acc[j][8 * m + 1]), ay = pack2(acc[j][8 * m + 2], acc[j][8 * m + 3]);
             uint32_t bx = pack2(acc[j][8 * m + 4], acc[j][8 * m + 5]), by = pack2(acc[j][8 * m + 6], acc[j][8 * m + 7]);
             const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
             const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-            if (valid) *reinterpret_cast<uint4 *>(yrow + 32 * j + 16 * m) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            uint32_t o[4] = {sx[0], sy[0], sx[1], sy[1]};
+            if (EPI == EPI_MASK_COLSUM) {
+                const uint4 mm = mk[2 * j + m];
+                const uint32_t mw[4] = {mm.x, mm.y, mm.z, mm.w};
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t keep = ((mw[q] & 0x7FFFu) ? 0xFFFFu : 0u) | ((mw[q] & 0x7FFF0000u) ? 0xFFFF0000u : 0u);
+                    o[q] = valid ? (o[q] & keep) : 0u;
+                    colacc[8 * (2 * j + m) + 2 * q] += __uint_as_float(o[q] << 16);
+                    colacc[8 * (2 * j + m) + 2 * q + 1] += __uint_as_float(o[q] & 0xFFFF0000u);
+                }
+            }
+            if (valid) *reinterpret_cast<uint4 *>(yrow + 32 * j + 16 * m) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
 }
@@ -119,15 +170,15 @@ k_linear(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ w
         __syncthreads();  // every wave is done with this buffer
         if (c + NBUF < n_chunks) dma_chunk(smem + (c % NBUF) * CHUNK_BYTES, w_slice, ldw, c + NBUF, w, lane);
     }
-    store_tile<HAS_BIAS>(acc, bias, y + (tok0 + r) * ldy + n0 + 8 * h, n0, h, valid);
+    store_tile<HAS_BIAS, EPI_NONE>(acc, bias, y + (tok0 + r) * ldy + n0 + 8 * h, n0, h, valid, Epi{}, 0, nullptr);
 }
 
 // K <= 256: the weight slice (<= 64 KiB) is loaded ONCE and stays in LDS; the workgroup then walks over token tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ... with the next half-row of B always in flight behind the current MFMAs.
-template <bool HAS_BIAS>
+template <bool HAS_BIAS, int EPI>
 __global__ void __launch_bounds__(THREADS, 2)
 k_linear_stationary(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ wgt, int64_t ldw,
-                    const float *__restrict__ bias, __bf16 *__restrict__ y, int64_t ldy, int64_t T, int K) {
+                    const float *__restrict__ bias, __bf16 *__restrict__ y, int64_t ldy, int64_t T, int K, Epi E) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * NS;
@@ -148,6 +199,13 @@ k_linear_stationary(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__r
     for (int ks = 0; ks < 8; ++ks) aoff[ks] = r * 256 + (((2 * ks + h) ^ (r & 15)) * 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (EPI == EPI_RELU_DROPOUT && E.seed_state) {
+        const uint64_t sd = *E.seed_state;  // same mixing as the other dropout kernels (g2048_layernorm.hip)
+        E.s0 ^= (uint32_t)sd * 0x9E3779B1u;
+        E.s1 += (uint32_t)(sd >> 32) * 0x85EBCA77u + (uint32_t)sd;
+    }
+    float colacc[EPI == EPI_MASK_COLSUM ? 64 : 1];
+    for (int q = 0; q < (EPI == EPI_MASK_COLSUM ? 64 : 1); ++q) colacc[q] = 0.f;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t next = tile + gridDim.x;
@@ -169,53 +227,119 @@ k_linear_stationary(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__r
                 }
         }
         const int64_t tok = tile * TOK + 32 * w + r;
-        store_tile<HAS_BIAS>(acc, bias, y + tok * ldy + n0 + 8 * h, n0, h, tok < T);
+        store_tile<HAS_BIAS, EPI>(acc, bias, y + tok * ldy + n0 + 8 * h, n0, h, tok < T, E, tok < T ? tok : T - 1, colacc);
         xrow = xnext;
     }
+    if (EPI == EPI_MASK_COLSUM) {
+        // column sums of this workgroup's tiles: lane (r, h) of wave w holds, for its tokens, columns
+        // 32j + 16m + 8h + e at colacc[8(2j + m) + e].  Through LDS (the weight image is no longer needed):
+        // red[w][q][lane], then thread c < 128 adds the 4 x 32 values of column c in a fixed order.
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem);
+        for (int q = 0; q < 64; ++q) red[(w * 64 + q) * 64 + lane] = colacc[q];
+        __syncthreads();
+        if (tid < NS) {
+            const int c = tid, q = 8 * (c >> 4) + (c & 7), hh = (c >> 3) & 1;
+            float sum = 0.f;
+            for (int ww = 0; ww < THREADS / 64; ++ww)
+                for (int rr = 0; rr < 32; ++rr) sum += red[(ww * 64 + q) * 64 + 32 * hh + rr];
+            E.partial[(int64_t)blockIdx.x * E.N + n0 + c] = sum;
+        }
+    }
+}
+
+}  // namespace
+
+namespace {
+
+inline bool operands_ok(const void *x, int64_t ldx, const void *weight, int64_t ldw, const void *y, int64_t ldy, int64_t T, int K,
+                        int N, const void *bias) {
+    return x && weight && y && T > 0 && K >= KC && K % KC == 0 && N >= NS && N % NS == 0 && ldx >= K && ldw >= K && ldy >= N &&
+           !(ldx & 7) && !(ldw & 7) && !(ldy & 7) && !(((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)bias) & 15);
+}
+
+// K <= 256: weights-stationary kernel, two workgroups per CU on 256 CUs shared between the N-slices
+template <bool HAS_BIAS, int EPI>
+int launch_stationary(const __bf16 *x, int64_t ldx, const __bf16 *w, int64_t ldw, const float *bias, __bf16 *y, int64_t ldy, int64_t T,
+                      int K, int N, const Epi &E, int *groups_out, hipStream_t stream) {
+    const void *fn = reinterpret_cast<const void *>(k_linear_stationary<HAS_BIAS, EPI>);
+    // the dynamic-LDS limit is a per-device attribute of the one kernel this call launches: set per call, no latch
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * CHUNK_BYTES) != hipSuccess)
+        return -(1000 + (int)hipGetLastError());
+    const int64_t n_tiles = (T + TOK - 1) / TOK;
+    const int slices = N / NS;
+    int64_t groups = 512 / slices;
+    if (groups < 1) groups = 1;
+    if (groups > n_tiles) groups = n_tiles;
+    if (groups_out) *groups_out = (int)groups;
+    // the column-sum epilogue reuses the whole 64 KiB as its reduction buffer
+    const int lds = EPI == EPI_MASK_COLSUM ? NBUF * CHUNK_BYTES : (K / KC) * CHUNK_BYTES;
+    hipLaunchKernelGGL((k_linear_stationary<HAS_BIAS, EPI>), dim3((unsigned)groups, (unsigned)slices), dim3(THREADS), lds, stream, x,
+                       ldx, w, ldw, bias, y, ldy, T, K, E);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(1000 + (int)e);
 }
 
 }  // namespace
 
 extern "C" int g2048_linear_bf16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const float *bias, void *y,
                                  int64_t ldy, int64_t T, int K, int N, void *stream) {
-    if (!x || !weight || !y || T <= 0 || K < KC || K % KC || N < NS || N % NS || ldx < K || ldw < K || ldy < N || (ldx & 7) ||
-        (ldw & 7) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)bias) & 15))
-        return G2048_EINVAL;
-    // the dynamic-LDS limit is a per-device attribute of the one kernel this call launches: set per call, no latch
-    {
-        const int lds = NBUF * CHUNK_BYTES;
-        const void *fn = K <= NBUF * KC ? (bias ? reinterpret_cast<const void *>(k_linear_stationary<true>)
-                                                : reinterpret_cast<const void *>(k_linear_stationary<false>))
-                                        : (bias ? reinterpret_cast<const void *>(k_linear<true>)
-                                                : reinterpret_cast<const void *>(k_linear<false>));
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return -(1000 + (int)hipGetLastError());
-    }
-    const int64_t n_tiles = (T + TOK - 1) / TOK;
-    const int slices = N / NS;
+    if (!operands_ok(x, ldx, weight, ldw, y, ldy, T, K, N, bias)) return G2048_EINVAL;
     const __bf16 *xp = (const __bf16 *)x, *wp = (const __bf16 *)weight;
     __bf16 *yp = (__bf16 *)y;
-    if (K <= NBUF * KC) {
-        // two workgroups per CU on 256 CUs, shared between the N-slices
-        int64_t groups = 512 / slices;
-        if (groups < 1) groups = 1;
-        if (groups > n_tiles) groups = n_tiles;
-        const dim3 grid((unsigned)groups, (unsigned)slices);
-        if (bias)
-            hipLaunchKernelGGL(k_linear_stationary<true>, grid, dim3(THREADS), (K / KC) * CHUNK_BYTES, (hipStream_t)stream, xp, ldx, wp,
-                               ldw, bias, yp, ldy, T, K);
-        else
-            hipLaunchKernelGGL(k_linear_stationary<false>, grid, dim3(THREADS), (K / KC) * CHUNK_BYTES, (hipStream_t)stream, xp, ldx, wp,
-                               ldw, bias, yp, ldy, T, K);
-    } else {
-        const dim3 grid((unsigned)n_tiles, (unsigned)slices);
-        if (bias)
-            hipLaunchKernelGGL(k_linear<true>, grid, dim3(THREADS), NBUF * CHUNK_BYTES, (hipStream_t)stream, xp, ldx, wp, ldw, bias, yp,
-                               ldy, T, K);
-        else
-            hipLaunchKernelGGL(k_linear<false>, grid, dim3(THREADS), NBUF * CHUNK_BYTES, (hipStream_t)stream, xp, ldx, wp, ldw, bias, yp,
-                               ldy, T, K);
-    }
+    if (K <= NBUF * KC)
+        return bias ? launch_stationary<true, EPI_NONE>(xp, ldx, wp, ldw, bias, yp, ldy, T, K, N, Epi{}, nullptr, (hipStream_t)stream)
+                    : launch_stationary<false, EPI_NONE>(xp, ldx, wp, ldw, bias, yp, ldy, T, K, N, Epi{}, nullptr, (hipStream_t)stream);
+    const void *fn = bias ? reinterpret_cast<const void *>(k_linear<true>) : reinterpret_cast<const void *>(k_linear<false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * CHUNK_BYTES) != hipSuccess)
+        return -(1000 + (int)hipGetLastError());
+    const dim3 grid((unsigned)((T + TOK - 1) / TOK), (unsigned)(N / NS));
+    if (bias)
+        hipLaunchKernelGGL(k_linear<true>, grid, dim3(THREADS), NBUF * CHUNK_BYTES, (hipStream_t)stream, xp, ldx, wp, ldw, bias, yp, ldy, T, K);
+    else
+        hipLaunchKernelGGL(k_linear<false>, grid, dim3(THREADS), NBUF * CHUNK_BYTES, (hipStream_t)stream, xp, ldx, wp, ldw, bias, yp, ldy, T,
+                           K);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(1000 + (int)e);
+}
+
+extern "C" int g2048_linear_relu_dropout_bf16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const float *bias, void *y,
+                                              int64_t ldy, int64_t T, int K, int N, float p_drop, uint64_t seed,
+                                              const uint64_t *seed_state, void *stream) {
+    if (!operands_ok(x, ldx, weight, ldw, y, ldy, T, K, N, bias) || !bias || K > NBUF * KC || !(p_drop >= 0.f && p_drop < 1.f))
+        return G2048_EINVAL;
+    Epi E{};
+    E.inv_keep = 1.0f / (1.0f - p_drop);
+    E.thr16 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+    E.s0 = (uint32_t)seed; E.s1 = (uint32_t)(seed >> 32);
+    E.seed_state = p_drop > 0.f ? seed_state : nullptr;
+    E.row_elems = N;
+    return launch_stationary<true, EPI_RELU_DROPOUT>((const __bf16 *)x, ldx, (const __bf16 *)weight, ldw, bias, (__bf16 *)y, ldy, T, K, N,
+                                                     E, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int64_t g2048_linear_mask_bwd_workspace_floats(int64_t T, int N) {
+    return (T <= 0 || N < NS || N % NS) ? 0 : (int64_t)512 * N;  // at most 512 / (N / 128) workgroup rows of N partial sums
+}
+
+extern "C" int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const void *weight_t, int64_t ldw, const void *y_saved,
+                                          int64_t ldm, void *dz, int64_t lddz, float *dbias, float *workspace, int64_t T, int K,
+                                          int N, float p_drop, void *stream) {
+    if (!operands_ok(dy, lddy, weight_t, ldw, dz, lddz, T, K, N, nullptr) || K > NBUF * KC || !y_saved || ldm < N || (ldm & 7) ||
+        !dbias || !workspace || (((uintptr_t)y_saved | (uintptr_t)workspace) & 15) || !(p_drop >= 0.f && p_drop < 1.f))
+        return G2048_EINVAL;
+    Epi E{};
+    E.inv_keep = 1.0f / (1.0f - p_drop);
+    E.mask = (const uint16_t *)y_saved;
+    E.ldm = ldm;
+    E.partial = workspace;
+    E.N = N;
+    int groups = 0;
+    const int rc = launch_stationary<false, EPI_MASK_COLSUM>((const __bf16 *)dy, lddy, (const __bf16 *)weight_t, ldw, nullptr, (__bf16 *)dz,
+                                                             lddz, T, K, N, E, &groups, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream,
+                       workspace, groups, N, dbias);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }

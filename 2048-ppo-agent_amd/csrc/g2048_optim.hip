@@ -59,12 +59,12 @@ struct StepArgs {
     int growth_interval;
 };
 
-__device__ __forceinline__ void adamw1(float &p, float g, float &m, float &v, float lr_wd, float w1, float b2, float step_size,
-                                       float inv_bc2_sqrt, float eps) {
+__device__ __forceinline__ void adamw1(float &p, float g, float &m, float &v, float lr_wd, float w1, float b2, float w2,
+                                       float step_size, float inv_bc2_sqrt, float eps) {
     p -= lr_wd * p;
     const float d = g - m;
     m = (w1 < 0.5f) ? m + w1 * d : g - d * (1.f - w1);  // at::lerp
-    v = b2 * v + (1.f - b2) * g * g;
+    v = b2 * v + w2 * g * g;
     const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
     p -= step_size * m / denom;
 }
@@ -94,17 +94,19 @@ k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const floa
             if (clip > 1.f) clip = 1.f;
         }
         const float t = steps[0] + 1.f;
-        const double bc1 = 1.0 - pow((double)G.beta1, (double)t), bc2 = 1.0 - pow((double)G.beta2, (double)t);
+        const double bc1 = 1.0 - pow(G.beta1, (double)t), bc2 = 1.0 - pow(G.beta2, (double)t);
         sh[0] = inv_scale;
         sh[1] = clip;
-        sh[2] = (float)((double)G.lr / bc1);
+        sh[2] = (float)(G.lr / bc1);
         sh[3] = (float)(1.0 / sqrt(bc2));
     }
     __syncthreads();
     const bool found_inf = scale != nullptr && !(fabsf(total) <= 3.4028234664e38f);  // inf or nan; without a scaler torch steps anyway
     if (!found_inf) {
         const float inv_scale = sh[0], clip = sh[1], step_size = sh[2], inv_bc2_sqrt = sh[3];
-        const float lr_wd = G.lr * G.weight_decay, w1 = 1.f - G.beta1;
+        // hyper-parameters arrive as f64 (what torch.optim holds) and are rounded once, after the f64 arithmetic on them
+        const float lr_wd = (float)(G.lr * G.weight_decay), w1 = (float)(1.0 - G.beta1), b2 = (float)G.beta2,
+                    w2 = (float)(1.0 - G.beta2), eps = (float)G.eps;
         float *p = c.param;
         const float *g = grads + c.offset;
         float *m = exp_avg + c.offset, *v = exp_avg_sq + c.offset;
@@ -113,17 +115,17 @@ k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const floa
                 float4 pv = *reinterpret_cast<float4 *>(p + i), mv = *reinterpret_cast<float4 *>(m + i),
                        vv = *reinterpret_cast<float4 *>(v + i);
                 const float4 gv = *reinterpret_cast<const float4 *>(g + i);
-                adamw1(pv.x, (gv.x * inv_scale) * clip, mv.x, vv.x, lr_wd, w1, G.beta2, step_size, inv_bc2_sqrt, G.eps);
-                adamw1(pv.y, (gv.y * inv_scale) * clip, mv.y, vv.y, lr_wd, w1, G.beta2, step_size, inv_bc2_sqrt, G.eps);
-                adamw1(pv.z, (gv.z * inv_scale) * clip, mv.z, vv.z, lr_wd, w1, G.beta2, step_size, inv_bc2_sqrt, G.eps);
-                adamw1(pv.w, (gv.w * inv_scale) * clip, mv.w, vv.w, lr_wd, w1, G.beta2, step_size, inv_bc2_sqrt, G.eps);
+                adamw1(pv.x, (gv.x * inv_scale) * clip, mv.x, vv.x, lr_wd, w1, b2, w2, step_size, inv_bc2_sqrt, eps);
+                adamw1(pv.y, (gv.y * inv_scale) * clip, mv.y, vv.y, lr_wd, w1, b2, w2, step_size, inv_bc2_sqrt, eps);
+                adamw1(pv.z, (gv.z * inv_scale) * clip, mv.z, vv.z, lr_wd, w1, b2, w2, step_size, inv_bc2_sqrt, eps);
+                adamw1(pv.w, (gv.w * inv_scale) * clip, mv.w, vv.w, lr_wd, w1, b2, w2, step_size, inv_bc2_sqrt, eps);
                 *reinterpret_cast<float4 *>(p + i) = pv;
                 *reinterpret_cast<float4 *>(m + i) = mv;
                 *reinterpret_cast<float4 *>(v + i) = vv;
             } else {
                 for (int k = i; k < c.n; ++k) {
                     float pk = p[k], mk = m[k], vk = v[k];
-                    adamw1(pk, (g[k] * inv_scale) * clip, mk, vk, lr_wd, w1, G.beta2, step_size, inv_bc2_sqrt, G.eps);
+                    adamw1(pk, (g[k] * inv_scale) * clip, mk, vk, lr_wd, w1, b2, w2, step_size, inv_bc2_sqrt, eps);
                     p[k] = pk; m[k] = mk; v[k] = vk;
                 }
             }

@@ -55,6 +55,9 @@ SIGNATURES = {
     "g2048_ppo_loss": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp,
                        _vp, _vp],
     "g2048_linear_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
+    "g2048_linear_relu_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_linear_mask_bwd_workspace_floats": [_i64, _i32],
+    "g2048_linear_mask_bwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp],
     "g2048_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_embed_bwd_workspace_floats": [_i64],
     "g2048_embed_bwd": [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
@@ -430,6 +433,40 @@ def linear_bf16(x2: torch.Tensor, weight: torch.Tensor, bias_f32=None, out=None)
     return out
 
 
+def linear_relu_dropout(x2: torch.Tensor, weight: torch.Tensor, bias_f32: torch.Tensor, p_drop: float, seed: int = 0,
+                        seed_state: int = 0) -> torch.Tensor:
+    """dropout(relu(x2 @ weight^T + bias)) -> bf16 [T, N] in one launch (K <= 256); see g2048_linear_relu_dropout_bf16."""
+    if not linear_ok(x2, weight) or x2.shape[1] > 256:
+        raise NativeError(f"linear_relu_dropout: unsupported operands {tuple(x2.shape)} {x2.dtype} x {tuple(weight.shape)}")
+    T, K = x2.shape
+    N = weight.shape[0]
+    out = torch.empty((T, N), dtype=torch.bfloat16, device=x2.device)
+    _check(load().g2048_linear_relu_dropout_bf16(x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0),
+                                                 _dev(bias_f32, f32, N, "bias"), out.data_ptr(), N, T, K, N, float(p_drop),
+                                                 int(seed) & (2 ** 64 - 1), seed_state or None, _stream()),
+           "g2048_linear_relu_dropout_bf16")
+    return out
+
+
+def linear_mask_bwd(dy2: torch.Tensor, weight_t: torch.Tensor, y_saved2: torch.Tensor, p_drop: float):
+    """-> (dz bf16 [T, N], dbias f32 [N]): dz = (dy2 @ weight_t^T) / (1 - p) where y_saved2 != 0; see
+    g2048_linear_mask_bwd_bf16."""
+    if not linear_ok(dy2, weight_t) or dy2.shape[1] > 256:
+        raise NativeError(f"linear_mask_bwd: unsupported operands {tuple(dy2.shape)} {dy2.dtype} x {tuple(weight_t.shape)}")
+    T, K = dy2.shape
+    N = weight_t.shape[0]
+    if tuple(y_saved2.shape) != (T, N) or y_saved2.dtype != torch.bfloat16 or y_saved2.stride(1) != 1 \
+            or y_saved2.stride(0) % 8 or y_saved2.data_ptr() % 16:
+        raise NativeError(f"linear_mask_bwd: y_saved {tuple(y_saved2.shape)} {y_saved2.dtype} does not match [{T}, {N}] bf16")
+    dz = torch.empty((T, N), dtype=torch.bfloat16, device=dy2.device)
+    db = torch.empty(N, dtype=f32, device=dy2.device)
+    ws = torch.empty(load().g2048_linear_mask_bwd_workspace_floats(T, N), dtype=f32, device=dy2.device)
+    _check(load().g2048_linear_mask_bwd_bf16(dy2.data_ptr(), dy2.stride(0), weight_t.data_ptr(), weight_t.stride(0),
+                                             y_saved2.data_ptr(), y_saved2.stride(0), dz.data_ptr(), N, db.data_ptr(),
+                                             ws.data_ptr(), T, K, N, float(p_drop), _stream()), "g2048_linear_mask_bwd_bf16")
+    return dz, db
+
+
 def embed_fwd(boards, wt, pe, cls, x0, p_drop: float = 0.0, seed: int = 0, seed_state: int = 0):
     M = boards.numel() // 16
     _check(load().g2048_embed_fwd(_dev(boards, u8, 16 * M, "boards"), _dev(wt, f32, 31 * 256, "wt"), _dev(pe, f32, 16 * 256, "pe"),
@@ -454,7 +491,7 @@ class OptChunk(C.Structure):  # g2048_opt_chunk
 
 
 class OptGroup(C.Structure):  # g2048_opt_group
-    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+    _fields_ = [("lr", _dbl), ("beta1", _dbl), ("beta2", _dbl), ("eps", _dbl), ("weight_decay", _dbl)]
 
 
 def opt_chunk_table(params, offsets, groups, device) -> torch.Tensor:

@@ -1,0 +1,107 @@
+"""The PPO update's optimiser step in two HIP launches (``g2048_opt_step``, csrc/g2048_optim.hip).
+
+The reference runs ``scaler.unscale_(opt); clip_grad_norm_(params, max_norm); scaler.step(opt); scaler.update()``
+(src/ppo/ppo_trainer.py:413-434) with ``opt = torch.optim.AdamW`` over two weight-decay groups
+(src/optim/configure_optimizers.py:16-127); PyTorch executes that as about a dozen multi-tensor launches per minibatch.
+``FlatAdamWStep`` keeps the SAME ``torch.optim.AdamW`` object (its ``param_groups`` drive the LR schedule, its
+``state_dict()`` is what checkpoints store) but owns the storage behind it: gradients, ``exp_avg`` and ``exp_avg_sq`` of all
+parameters live in three flat f32 buffers, ``optimizer.state[p]`` holds views into them, and ``step()`` is one call into the
+kernel pair.  The flat gradient buffer doubles as the all-reduce bucket of a multi-GPU run.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..g2048 import native as nv
+
+
+class FlatAdamWStep:
+    @staticmethod
+    def supports(optimizer, device) -> bool:
+        """A plain AdamW over contiguous f32 parameters on the HIP device, at most ``OPT_MAX_GROUPS`` groups."""
+        if type(optimizer) is not torch.optim.AdamW or torch.device(device).type != "cuda":
+            return False
+        if len(optimizer.param_groups) > nv.OPT_MAX_GROUPS:
+            return False
+        for g in optimizer.param_groups:
+            if g.get("amsgrad") or g.get("maximize") or isinstance(g["lr"], torch.Tensor):
+                return False
+            for p in g["params"]:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    return False
+        return True
+
+    def __init__(self, optimizer: torch.optim.AdamW, device):
+        if not self.supports(optimizer, device):
+            raise ValueError("FlatAdamWStep needs a torch.optim.AdamW over contiguous f32 parameters on the HIP device")
+        self.optimizer, self.device = optimizer, torch.device(device)
+        self.params, self.group_of = [], []
+        for gi, g in enumerate(optimizer.param_groups):
+            for p in g["params"]:
+                if p.requires_grad:
+                    self.params.append(p)
+                    self.group_of.append(gi)
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4  # every tensor starts on a 16-byte boundary of the flat buffers
+        self.numel = n
+        z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.grad, self.exp_avg, self.exp_avg_sq = z(), z(), z()
+        self.steps = torch.zeros(len(self.params), dtype=torch.float32, device=self.device)
+        view = lambda flat: [flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
+        self.grad_views, self.m_views, self.v_views = view(self.grad), view(self.exp_avg), view(self.exp_avg_sq)
+        self.info = torch.zeros(2, dtype=torch.float32, device=self.device)  # [grad norm before clipping, found_inf]
+        self._table_key, self._table, self._n_chunks, self._ws = None, None, 0, None
+        self.adopt_state()
+
+    # ------------------------------------------------------------------ state <-> torch.optim
+    def adopt_state(self):
+        """Take over whatever ``optimizer.state`` holds (fresh: nothing; after ``load_state_dict``: loaded tensors) and
+        re-point it at the flat buffers."""
+        st = self.optimizer.state
+        for i, p in enumerate(self.params):
+            s = st.get(p, {})
+            m, v, t = s.get("exp_avg"), s.get("exp_avg_sq"), s.get("step")
+            with torch.no_grad():
+                if m is not None and m.data_ptr() != self.m_views[i].data_ptr():
+                    self.m_views[i].copy_(m)
+                elif m is None:
+                    self.m_views[i].zero_()
+                if v is not None and v.data_ptr() != self.v_views[i].data_ptr():
+                    self.v_views[i].copy_(v)
+                elif v is None:
+                    self.v_views[i].zero_()
+                if t is None:
+                    self.steps[i] = 0.0
+                elif not (torch.is_tensor(t) and t.data_ptr() == self.steps[i].data_ptr()):
+                    self.steps[i] = float(t)
+            st[p] = {"step": self.steps[i], "exp_avg": self.m_views[i], "exp_avg_sq": self.v_views[i]}
+
+    def _chunk_table(self):
+        key = tuple(p.data_ptr() for p in self.params)
+        if key != self._table_key:  # a parameter was re-allocated (module.to(), load with assign=True, ...)
+            self._table = nv.opt_chunk_table(self.params, self.offsets, self.group_of, self.device)
+            self._n_chunks = self._table.numel() // 24
+            self._ws = nv.opt_workspace(self._n_chunks, self.device)
+            self._table_key = key
+        return self._table
+
+    # ------------------------------------------------------------------ the step
+    def step(self, max_grad_norm, scaler=None):
+        """Gradients are read from ``self.grad`` (bind ``p.grad`` to ``grad_views`` or copy into them first)."""
+        table = self._chunk_table()
+        groups = []
+        for g in self.optimizer.param_groups:
+            b1, b2 = g["betas"]
+            groups.append((g["lr"], b1, b2, g["eps"], g["weight_decay"]))
+        scale = tracker = None
+        growth, backoff, interval = 2.0, 0.5, 2000
+        if scaler is not None and scaler.is_enabled():
+            if scaler._scale is None:
+                scaler._lazy_init_scale_growth_tracker(self.device)
+            scale, tracker = scaler._scale, scaler._growth_tracker
+            growth, backoff, interval = scaler.get_growth_factor(), scaler.get_backoff_factor(), scaler.get_growth_interval()
+        nv.opt_step(table, self._n_chunks, self.grad, self.exp_avg, self.exp_avg_sq, groups, max_grad_norm, self.steps, scale,
+                    tracker, growth, backoff, interval, self._ws, self.info)
+        self.optimizer._opt_called = True  # the LR scheduler checks that a step preceded scheduler.step()

@@ -110,6 +110,28 @@ def _hip_linear(x2: torch.Tensor, wb: torch.Tensor, bias_f32=None):
     return nv.linear_bf16(x2, wb, bias_f32)
 
 
+def _stationary_ok(x2: torch.Tensor, wb: torch.Tensor) -> bool:
+    """The shapes of the fused feed-forward kernels (weights-stationary GEMM: K <= 256, wide output, many tokens)."""
+    K, N = x2.shape[-1], wb.shape[0]
+    if K > 256 or N < 512 or N % 256 or x2.shape[0] < 4096:
+        return False
+    from ..g2048 import native as nv
+
+    return nv.linear_ok(x2, wb)
+
+
+class FFNLink:
+    """Shared by the two autograd nodes of one feed-forward block (``_LinearReluDropout`` -> ``_LinearAddLayerNorm``): the
+    backward of the second computes linear2's input gradient already masked by the saved activation and with linear1's
+    bias gradient (``g2048_linear_mask_bwd_bf16``) and leaves both here for the backward of the first, which then has
+    nothing left to launch for the activation."""
+
+    __slots__ = ("p_drop", "db", "masked")
+
+    def __init__(self, p_drop: float):
+        self.p_drop, self.db, self.masked = float(p_drop), None, False
+
+
 def _dweight(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """dW = dY^T X in f32 from bf16 operands.  It reduces over every token of the minibatch (34 816 at minibatch 2048)
     into a tiny [out, in] matrix; hipBLASLt runs that as 16-64 workgroups on 256 CUs (177 us per GEMM).  Cutting the
@@ -350,12 +372,12 @@ class _LinearAddLayerNorm(torch.autograd.Function):
     masters weight/bias, x f32; returns (x_new, h)."""
 
     @staticmethod
-    def forward(ctx, u, weight, bias, wb, bb, x, gamma, beta, eps, p_drop, wbT=None):
+    def forward(ctx, u, weight, bias, wb, bb, x, gamma, beta, eps, p_drop, wbT=None, link=None):
         from ..g2048 import native as nv
 
         with torch.autocast("cuda", enabled=False):
             a = F.linear(u, wb, bb)
-        ctx.wbT = wbT
+        ctx.wbT, ctx.link = wbT, link
         x, row_stride = _residual_rows(x)
         T = x.numel() // 256
         gamma, beta = gamma.contiguous(), beta.contiguous()
@@ -385,29 +407,42 @@ class _LinearAddLayerNorm(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             da2, u2 = da.view(T, 256), u.reshape(T, -1)
             du = None
+            link = ctx.link
             if ctx.needs_input_grad[0]:
-                du = _hip_linear(da2, ctx.wbT) if ctx.wbT is not None else None
-                du = (da2 @ wb if du is None else du).view(u.shape)
+                if link is not None and ctx.wbT is not None and _stationary_ok(da2, ctx.wbT):
+                    # u = dropout(relu(.)) of the same block: mask + 1/keep + linear1's bias gradient in the GEMM epilogue
+                    du, link.db = nv.linear_mask_bwd(da2, ctx.wbT, u2, link.p_drop)
+                    link.masked = True
+                    du = du.view(u.shape)
+                else:
+                    du = _hip_linear(da2, ctx.wbT) if ctx.wbT is not None else None
+                    du = (da2 @ wb if du is None else du).view(u.shape)
             dw = _dweight(da2, u2)
-        return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None
+        return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None, None
 
 
 class _LinearReluDropout(torch.autograd.Function):
-    """``dropout(relu(Linear(h)))`` (linear1 of the feed-forward block): the activation is one kernel each way
-    (``g2048_relu_dropout_fwd/bwd``), only the OUTPUT is saved (it is non-zero exactly where the unit was active and
-    kept), and the backward kernel also yields the bias gradient."""
+    """``dropout(relu(Linear(h)))`` (linear1 of the feed-forward block).  At the update's shapes the whole thing is one
+    GEMM with a fused epilogue (``g2048_linear_relu_dropout_bf16``), otherwise a GEMM plus ``g2048_relu_dropout_fwd``.  Only
+    the OUTPUT is saved (it is non-zero exactly where the unit was active and kept).  Backward: when the consumer
+    (``_LinearAddLayerNorm`` of the same block, via ``link``) already delivered the masked gradient and the bias
+    gradient, nothing is launched for the activation; else ``g2048_relu_dropout_bwd``."""
 
     @staticmethod
-    def forward(ctx, h, weight, bias, wb, bb, p_drop):
+    def forward(ctx, h, weight, bias, wb, bb, p_drop, link=None):
         from ..g2048 import native as nv
 
+        h2 = h.reshape(-1, h.shape[-1])
         with torch.autocast("cuda", enabled=False):
-            z = _hip_linear(h.reshape(-1, h.shape[-1]), wb, bias)
-            z = F.linear(h, wb, bb) if z is None else z.view(*h.shape[:-1], wb.shape[0])
-        y = torch.empty_like(z)
-        nv.relu_dropout_fwd(z, y, p_drop, *_seed_pair(z, p_drop))
+            if _stationary_ok(h2, wb) and bias.dtype == torch.float32:
+                y = nv.linear_relu_dropout(h2, wb, bias.detach(), p_drop, *_seed_pair(h2, p_drop)).view(*h.shape[:-1], wb.shape[0])
+            else:
+                z = _hip_linear(h2, wb, bias)
+                z = F.linear(h, wb, bb) if z is None else z.view(*h.shape[:-1], wb.shape[0])
+                y = torch.empty_like(z)
+                nv.relu_dropout_fwd(z, y, p_drop, *_seed_pair(z, p_drop))
         ctx.save_for_backward(h, wb, y)
-        ctx.p_drop = p_drop
+        ctx.p_drop, ctx.link = p_drop, link
         return y
 
     @staticmethod
@@ -415,14 +450,19 @@ class _LinearReluDropout(torch.autograd.Function):
         from ..g2048 import native as nv
 
         h, wb, y = ctx.saved_tensors
-        dz = torch.empty_like(y)
-        db = torch.empty(y.shape[-1], dtype=torch.float32, device=y.device)
-        nv.relu_dropout_bwd(dy.contiguous(), y, dz, db, ctx.p_drop)
+        link = ctx.link
+        if link is not None and link.masked:
+            dz, db = dy.contiguous(), link.db
+            link.db, link.masked = None, False
+        else:
+            dz = torch.empty_like(y)
+            db = torch.empty(y.shape[-1], dtype=torch.float32, device=y.device)
+            nv.relu_dropout_bwd(dy.contiguous(), y, dz, db, ctx.p_drop)
         with torch.autocast("cuda", enabled=False):
             dz2, h2 = dz.view(-1, dz.shape[-1]), h.reshape(-1, h.shape[-1])
             dh = (dz2 @ wb).view(h.shape) if ctx.needs_input_grad[0] else None
             dw = _dweight(dz2, h2)
-        return dh, dw, db, None, None, None
+        return dh, dw, db, None, None, None, None
 
 
 def _fused_norm_ok(x: torch.Tensor, a) -> bool:

@@ -22,6 +22,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 from torch.amp import GradScaler, autocast
 
+from ..optim.flat_step import FlatAdamWStep
 from ..optim import configure_bert_optimizers
 from ..runs.batch_runner import BatchRunner
 from .data_loader import DeviceBatches, PPODataset
@@ -215,8 +216,15 @@ class PPOTrainer:
         self.rank = dist.get_rank() if self.world > 1 else 0
         self._group = dist.group.WORLD if self.world > 1 else None
         self._flat_grad = None
-        if self.world > 1:
+        # clip + AdamW + GradScaler bookkeeping as one kernel pair over flat buffers (g2048_opt_step) for the reference's
+        # default optimiser on the device; anything else (LAMB, Adam, CPU) takes the PyTorch calls of the reference
+        self._flat_step = None
+        if os.environ.get("G2048_FLAT_OPT", "1").strip().lower() not in ("0", "false", "no", "off") \
+                and FlatAdamWStep.supports(self.optimizer, self.device):
+            self._flat_step = FlatAdamWStep(self.optimizer, self.device)
+        if self.world > 1 or self._flat_step is not None:
             self._bind_flat_grads()
+        if self.world > 1:
             self._broadcast_parameters()
 
         # forward + loss + backward of one minibatch replayed as a hipGraph: the update is ~330 small kernels per
@@ -248,6 +256,13 @@ class PPOTrainer:
         """One contiguous gradient bucket for the single all-reduce per step; ``_flat_views[i]`` is the slice of
         parameter i.  Backward writes fresh ``.grad`` tensors (no accumulate kernel per parameter) which
         ``_collect_grads`` gathers into the bucket with one multi-tensor copy and then re-points ``.grad`` at."""
+        if self._flat_step is not None:  # the optimiser kernel's gradient buffer IS the bucket
+            self._params, self._flat_grad = self._flat_step.params, self._flat_step.grad
+            self._flat_views = self._flat_step.grad_views
+            self._flat_grad.zero_()
+            for p in self._params:
+                p.grad = None
+            return
         self._params = [p for p in self.agent.parameters() if p.requires_grad]
         total = sum(p.numel() for p in self._params)
         self._flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
@@ -280,8 +295,9 @@ class PPOTrainer:
         self.optimizer.zero_grad(set_to_none=True)
 
     def _allreduce_grads(self):
-        if self.world > 1:
+        if self._flat_grad is not None:
             self._collect_grads()  # no-op for gradients that already live in the bucket (hipGraph replay)
+        if self.world > 1:
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self._group)
             self._flat_grad.div_(self.world)
 
@@ -512,7 +528,9 @@ class PPOTrainer:
                         graphed = self._graphs.get(gkey) or self._build_graph(gkey, batch_size, sample)
                     stats, kl = graphed.run(sample) if graphed is not None else self._loss_backward(**sample)
                 self._allreduce_grads()
-                if self.use_amp:
+                if self._flat_step is not None:
+                    self._flat_step.step(self.max_grad_norm, self.scaler if self.use_amp else None)
+                elif self.use_amp:
                     self.scaler.unscale_(self.optimizer)
                     torch.nn.utils.clip_grad_norm_(self.agent.parameters(), self.max_grad_norm)
                     self.scaler.step(self.optimizer)
@@ -581,6 +599,8 @@ class PPOTrainer:
                 self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
             except Exception as e:  # keep training with a fresh optimizer, as the reference does
                 logger.warning("Failed to load optimizer state: %s", e)
+            if self._flat_step is not None:
+                self._flat_step.adopt_state()
         self.total_timesteps = ckpt.get("total_timesteps", 0)
         self.total_epochs = ckpt.get("total_epochs", 0)
         self.total_update_steps = ckpt.get("total_update_steps", 0)

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from ..env_definitions import BOARD_DIM
 
-from .hip_ops import (Bf16Shadow, _AddLayerNorm, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
+from .hip_ops import (Bf16Shadow, FFNLink, _AddLayerNorm, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
                       _LinearAddLayerNorm, _LinearReluDropout, _LinearSplitK, _add_norm, _fused_attention_ok, _fused_norm_ok,
                       _linear, _train_bf16, graph_seed_state)
 
@@ -129,12 +129,13 @@ class TransformerEncoder(nn.Module):
             n2 = layer.norm2
             x, h = _LinearAddLayerNorm.apply(a, attn.out_proj.weight, attn.out_proj.bias, sh[2], sh[3], x, n2.weight,
                                              n2.bias, n2.eps, p)
-            f = _LinearReluDropout.apply(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5], p)
+            link = FFNLink(p) if next_norm is not None else None
+            f = _LinearReluDropout.apply(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5], p, link)
             if next_norm is None:
                 f = _linear(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7])
                 return x + F.dropout(f, p, self.training), None
             return _LinearAddLayerNorm.apply(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7], x, next_norm.weight,
-                                             next_norm.bias, next_norm.eps, p, sh[8])
+                                             next_norm.bias, next_norm.eps, p, sh[8], link)
         a = _linear(a, attn.out_proj.weight, attn.out_proj.bias, sh[2], sh[3])
         x, h = _add_norm(x, a, layer.norm2, p, self.training)
         f = F.dropout(F.relu(_linear(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5])), p, self.training)

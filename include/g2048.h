@@ -273,6 +273,23 @@ int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias
 int g2048_linear_bf16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const float *bias, void *y, int64_t ldy,
                       int64_t T, int K, int N, void *stream);
 
+/* y = dropout(relu(x . weight^T + bias)) in one launch: linear1 + activation + dropout of the encoder layer's feed-forward
+ * block (reference: nn.TransformerEncoderLayer._ff_block, built at src/ppo/transformer_encoder.py:138-148).  Operands as
+ * for g2048_linear_bf16 with K <= 256 and bias required; the pre-activation is never rounded to bf16.  seed / seed_state
+ * as for g2048_attn_fwd.  The output is non-zero exactly where the unit was active and kept. */
+int g2048_linear_relu_dropout_bf16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const float *bias, void *y,
+                                   int64_t ldy, int64_t T, int K, int N, float p_drop, uint64_t seed,
+                                   const uint64_t *seed_state, void *stream);
+/* The backward of `y_saved = dropout(relu(.)); out = y_saved . W2^T` with respect to the pre-activation, in one GEMM:
+ * dz[T][N] = (dy[T][K] . weight_t[N][K]^T) / (1 - p_drop) where y_saved != 0, else 0 (weight_t = W2^T, i.e. linear2's
+ * weight [K][N] transposed to [N][K]; dy = the gradient of linear2's output), and dbias f32 [N] = column sums of the bf16
+ * dz in a fixed order = linear1's bias gradient.  Replaces g2048_linear_bf16 + g2048_relu_dropout_bwd.  K <= 256;
+ * y_saved bf16 [T][ldm]; workspace: g2048_linear_mask_bwd_workspace_floats(T, N) floats. */
+int64_t g2048_linear_mask_bwd_workspace_floats(int64_t T, int N);
+int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const void *weight_t, int64_t ldw, const void *y_saved, int64_t ldm,
+                               void *dz, int64_t lddz, float *dbias, float *workspace, int64_t T, int K, int N, float p_drop,
+                               void *stream);
+
 /* ---- policy network (update): token embedding of packed boards ---------------------------------------------- */
 
 /* x0[m][0] = cls, x0[m][1 + c] = dropout(wt[boards[m][c]] + pe[c]): the bias-free input Linear over the one-hot cell (wt =
@@ -312,7 +329,7 @@ int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, fl
 #define G2048_OPT_CHUNK 2048
 #define G2048_OPT_MAX_GROUPS 4
 typedef struct { float *param; int64_t offset; int32_t n; int32_t group; } g2048_opt_chunk;
-typedef struct { float lr, beta1, beta2, eps, weight_decay; } g2048_opt_group;
+typedef struct { double lr, beta1, beta2, eps, weight_decay; } g2048_opt_group; /* f64, as torch.optim holds them */
 int64_t g2048_opt_workspace_floats(int n_chunks);
 int g2048_opt_step(const g2048_opt_chunk *chunks, int n_chunks, const float *grads, float *exp_avg, float *exp_avg_sq,
                    const g2048_opt_group *groups, int n_groups, float max_grad_norm, float *steps, int n_steps, float *scale,

@@ -106,7 +106,7 @@ def _worker_default_shape(rank, world, port, results):
         gr = _GraphedFwdBwd(tr, M, {k: v.contiguous() for k, v in mine.items()})
         gr.run({k: v.contiguous() for k, v in mine.items()})
         tr._allreduce_grads()
-        got = tr._flat_grad.clone()
+        got = torch.cat([v.flatten() for v in tr._flat_views])  # (the bucket pads every tensor to 16 bytes)
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(tr._params, tr._flat_views)), "grads must live in the bucket"
         # the single-process answer: the mean of the two half-batch gradients (equal halves -> the full-batch mean loss)
         want = torch.zeros_like(got)

@@ -1,0 +1,167 @@
+"""g2048_opt_step (clip + AdamW + GradScaler in two launches) against the PyTorch calls of the reference's update loop
+(src/ppo/ppo_trainer.py:413-434): scaler.unscale_, clip_grad_norm_, scaler.step(AdamW), scaler.update."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from torch.amp import GradScaler
+
+from src.optim import configure_bert_optimizers
+from src.optim.flat_step import FlatAdamWStep
+from src.ppo import PPOAgent, PPOTrainer, RolloutBuffer
+from src.runs import BatchRunner
+
+pytestmark = pytest.mark.gpu
+OPTIM = dict(opt_name="adamw", max_lr=4e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, warmup_steps_ratio=0.025,
+             scheduler_names=["linear", "cosine"], blacklist_weight_modules=["norm", "embedding"])
+
+
+class _Net(nn.Module):
+    """Shapes that exercise the chunk table: > 1 chunk, ragged tails (numel % 4 != 0), a scalar, both decay groups."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(300, 41)       # 12 300 weights: 7 chunks with a ragged tail, bias 41
+        self.norm = nn.LayerNorm(41)      # no-decay group
+        self.b = nn.Linear(41, 1)         # bias of one element
+        self.embedding = nn.Embedding(7, 3)
+        self.big = nn.Parameter(torch.randn(5000, 3))
+
+
+def _pair(dev, with_scaler):
+    torch.manual_seed(3)
+    net_t = _Net().to(dev)
+    net_f = copy.deepcopy(net_t)
+    mk = lambda net: configure_bert_optimizers(net, steps=50, **OPTIM)
+    ot, of = mk(net_t), mk(net_f)
+    st = GradScaler(init_scale=1024.0, growth_interval=3) if with_scaler else None
+    sf = GradScaler(init_scale=1024.0, growth_interval=3) if with_scaler else None
+    flat = FlatAdamWStep(of["optimizer"], dev)
+    return net_t, net_f, ot, of, st, sf, flat
+
+
+@pytest.mark.parametrize("with_scaler", [True, False])
+def test_flat_step_matches_torch_sequence(dev, with_scaler):
+    net_t, net_f, ot, of, st, sf, flat = _pair(dev, with_scaler)
+    opt_t, opt_f = ot["optimizer"], of["optimizer"]
+    sch_t, sch_f = ot["lr_scheduler"]["scheduler"], of["lr_scheduler"]["scheduler"]
+    max_norm = 0.5
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for it in range(10):
+        scale = float(st.get_scale()) if with_scaler else 1.0
+        big = 30.0 if it % 2 else 0.01  # norms on both sides of the clip threshold
+        grads = [torch.randn(p.shape, generator=g).to(dev) * big for p in net_t.parameters()]
+        if with_scaler and it in (4, 5):  # two consecutive overflow steps: skipped, scale halves twice
+            grads[2][0] = float("inf") if it == 4 else float("nan")
+        by_param = {id(q): gr for q, gr in zip(net_f.parameters(), grads)}
+        for p, gr in zip(net_t.parameters(), grads):
+            p.grad = gr * scale
+        for v, q in zip(flat.grad_views, flat.params):  # the flat layout is ordered by parameter group
+            v.copy_(by_param[id(q)] * scale)
+        if with_scaler:
+            st.scale(torch.zeros(1, device=dev))  # lazy init of the scale, as scaler.scale(loss) does in the loop
+            st.unscale_(opt_t)
+            torch.nn.utils.clip_grad_norm_(net_t.parameters(), max_norm)
+            st.step(opt_t)
+            st.update()
+        else:
+            torch.nn.utils.clip_grad_norm_(net_t.parameters(), max_norm)
+            opt_t.step()
+        flat.step(max_norm, sf)
+        sch_t.step()
+        sch_f.step()
+        if with_scaler:
+            assert float(st.get_scale()) == float(sf.get_scale()), it
+            assert int(st._growth_tracker.item()) == int(sf._growth_tracker.item()), it
+            assert bool(flat.info[1].item()) == (it in (4, 5))
+        for (n, p), q in zip(net_t.named_parameters(), net_f.parameters()):
+            assert torch.allclose(p, q, rtol=2e-6, atol=1e-8), (it, n, (p - q).abs().max().item())
+    # moments and step counts in the optimiser's own state (what a checkpoint stores)
+    for p, q in zip(net_t.parameters(), net_f.parameters()):
+        a, b = opt_t.state[p], opt_f.state[q]
+        assert float(a["step"]) == float(b["step"]) == (8 if with_scaler else 10)
+        # (sums with cancellation: the absolute error scales with the largest term, not with the result)
+        assert torch.allclose(a["exp_avg"], b["exp_avg"], rtol=2e-6, atol=1e-6 * float(a["exp_avg"].abs().max()))
+        assert torch.allclose(a["exp_avg_sq"], b["exp_avg_sq"], rtol=2e-6, atol=1e-6 * float(a["exp_avg_sq"].abs().max()))
+    if with_scaler:
+        assert float(sf.get_scale()) == 1024.0 * 2 / 4 * 2  # grew after 3 clean steps, halved twice, grew again
+
+
+def test_flat_step_state_dict_round_trip(dev):
+    """optimizer.state_dict() of the flat step loads into a plain AdamW and back (checkpoint interchange)."""
+    net_t, net_f, ot, of, st, sf, flat = _pair(dev, False)
+    for v in flat.grad_views:
+        v.normal_()
+    flat.step(0.5, None)
+    flat.step(0.5, None)
+    sd = copy.deepcopy(of["optimizer"].state_dict())
+    ot["optimizer"].load_state_dict(sd)  # plain torch optimiser takes it
+    for p, q in zip(net_t.parameters(), net_f.parameters()):
+        assert torch.equal(ot["optimizer"].state[p]["exp_avg"], of["optimizer"].state[q]["exp_avg"])
+        assert float(ot["optimizer"].state[p]["step"]) == 2.0
+    # and back: a freshly built flat step adopts a loaded state
+    net_n = copy.deepcopy(net_f)
+    on = configure_bert_optimizers(net_n, steps=50, **OPTIM)
+    flat_n = FlatAdamWStep(on["optimizer"], dev)
+    on["optimizer"].load_state_dict(sd)
+    flat_n.adopt_state()
+    assert torch.equal(flat_n.exp_avg, flat.exp_avg) and torch.equal(flat_n.exp_avg_sq, flat.exp_avg_sq)
+    assert torch.equal(flat_n.steps, flat.steps) and float(flat_n.steps[0]) == 2.0
+    for v, w in zip(flat.grad_views, flat_n.grad_views):
+        w.copy_(v)
+    flat.step(0.5, None)
+    flat_n.step(0.5, None)
+    for p, q in zip(net_f.parameters(), net_n.parameters()):
+        assert torch.equal(p, q)
+
+
+def _trainer(dev, agent, log_dir, **kw):
+    optim = dict(OPTIM, scheduler_names=["constant", "constant"])
+    args = dict(gamma=0.99, lambda_gae=0.95, clip_epsilon=0.2, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5,
+                target_kl=10.0, use_action_mask=True, device=dev, mixed_precision="bfloat16", max_samples_per_epoch=1024,
+                shuffle_on_reset=False, log_dir=str(log_dir))
+    args.update(kw)
+    return PPOTrainer(agent, BatchRunner(init_seed=0), RolloutBuffer(31, 16, 4), optim, max_steps=1000, **args)
+
+
+def test_trainer_update_with_flat_step_matches_torch_step(dev, tmp_path, monkeypatch):
+    """The same rollouts and minibatches through update_policy with the kernel pair and with PyTorch's calls
+    (G2048_FLAT_OPT=0): parameters agree to f32 rounding after several optimiser steps (dropout off, eager mode)."""
+    monkeypatch.chdir(tmp_path)
+
+    def run(flat):
+        monkeypatch.setenv("G2048_FLAT_OPT", "1" if flat else "0")
+        torch.manual_seed(5)
+        agent = PPOAgent(hidden_dim=64, d_model=64, nhead=4, num_layers=2, dim_feedforward=128, dropout=0.0, reduction="cls")
+        tr = _trainer(dev, agent, tmp_path / ("f" if flat else "t"), use_hip_graph=False)
+        assert (tr._flat_step is not None) == flat
+        tr.collect_rollouts(batch_size=64, num_batches=1)
+        torch.manual_seed(6)
+        m = tr.update_policy(batch_size=256, n_epochs=2)
+        return tr, m
+
+    torch.manual_seed(5)
+    init = PPOAgent(hidden_dim=64, d_model=64, nhead=4, num_layers=2, dim_feedforward=128, dropout=0.0, reduction="cls")
+    p0 = torch.cat([p.detach().flatten() for p in init.parameters()]).to(dev)
+    tr_f, m_f = run(True)
+    tr_t, m_t = run(False)
+    assert m_f["n_updates"] == m_t["n_updates"] >= 4
+    # element-wise equality is not to be had over several steps (AdamW's m / sqrt(v) amplifies the last-bit differences
+    # of the bf16 forward for elements whose gradient is near zero; the arithmetic itself is pinned by
+    # test_flat_step_matches_torch_sequence): the two parameter displacements must coincide as vectors
+    df = torch.cat([p.detach().flatten() for p in tr_f.agent.parameters()]) - p0
+    dt = torch.cat([p.detach().flatten() for p in tr_t.agent.parameters()]) - p0
+    assert df.norm() > 0 and (df - dt).norm() / dt.norm() < 2e-2, ((df - dt).norm() / dt.norm()).item()
+    np.testing.assert_allclose(m_f["total_loss"], m_t["total_loss"], rtol=1e-3, atol=1e-5)
+    # checkpoint written with the flat step loads into the PyTorch-step trainer and the other way round
+    tr_f.save_checkpoint(str(tmp_path / "f.pt"))
+    tr_t.load_checkpoint(str(tmp_path / "f.pt"), load_optimizer=True)
+    p0 = next(iter(tr_t.agent.parameters()))
+    assert float(tr_t.optimizer.state[p0]["step"]) == m_f["n_updates"]
+    tr_t.save_checkpoint(str(tmp_path / "t.pt"))
+    tr_f.load_checkpoint(str(tmp_path / "t.pt"), load_optimizer=True)
+    assert float(tr_f._flat_step.steps[0]) == m_f["n_updates"]
+    m2 = tr_f.update_policy(batch_size=256, n_epochs=1)  # and keeps training
+    assert m2["n_updates"] >= 2 and np.isfinite(m2["total_loss"])

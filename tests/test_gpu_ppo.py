@@ -561,6 +561,99 @@ def test_fused_linear_blocks_match_torch(dev):
             assert rel(g, t.grad) < 2e-2, (name, rel(g, t.grad))  # units with z ~ 0 may land on either side of the ReLU
 
 
+def test_fused_ffn_kernels(dev):
+    """g2048_linear_relu_dropout_bf16 and g2048_linear_mask_bwd_bf16 (GEMM + activation epilogues) vs f32 references: ragged
+    T, dropout off (values) and on (keep rate, scaling, no structure, new masks per seed), masked gradient and the bias
+    gradient (column sums of the bf16 result, bit-reproducible)."""
+    import torch.nn.functional as F
+
+    from src.g2048 import native as nv
+
+    torch.manual_seed(23)
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    for T in (1, 130, 4096, 34816 + 3):
+        for K, N in ((256, 1024), (256, 512), (128, 128)):
+            x = torch.randn(T, K, device=dev).to(torch.bfloat16)
+            w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+            b = 0.2 * torch.randn(N, device=dev)
+            ref = torch.relu(F.linear(x.float(), w.float(), b))
+            y = nv.linear_relu_dropout(x, w, b, 0.0)
+            assert y.shape == (T, N) and rel(y, ref) < 4e-3, (T, K, N, rel(y, ref))
+            assert ((y == 0) == (ref.to(torch.bfloat16) == 0)).float().mean() > 0.999  # pre-activations next to 0 may differ
+            if T >= 4096:
+                y1, y2 = nv.linear_relu_dropout(x, w, b, 0.1, seed=7), nv.linear_relu_dropout(x, w, b, 0.1, seed=8)
+                assert torch.equal(y1, nv.linear_relu_dropout(x, w, b, 0.1, seed=7)) and not torch.equal(y1, y2)
+                active, kept = y != 0, y1 != 0
+                assert not (kept & ~active).any()
+                assert abs(kept[active].float().mean().item() - 0.9) < 3e-3
+                assert torch.allclose(y1[kept].float(), ref[kept] / 0.9, rtol=2e-2, atol=2e-2)
+                assert (kept.float().sum(0) / active.float().sum(0).clamp_min(1) - 0.9).abs().max() < 0.06
+                assert (kept.float().sum(1) / active.float().sum(1).clamp_min(1) - 0.9).abs().mean() < 0.05
+            # backward: dz = (dy @ W2) / keep where y_saved != 0
+            dy = torch.randn(T, K, device=dev).to(torch.bfloat16)
+            w2t = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)  # = linear2.weight^T, [N, K]
+            for p, ys in ((0.0, y), (0.1, nv.linear_relu_dropout(x, w, b, 0.1, seed=9))):
+                dz, db = nv.linear_mask_bwd(dy, w2t, ys, p)
+                want = torch.where(ys != 0, (dy.float() @ w2t.float().t()) / (1 - p), torch.zeros((), device=dev))
+                assert rel(dz, want) < 4e-3, (T, K, N, p, rel(dz, want))
+                assert not (dz[ys == 0] != 0).any()
+                assert torch.allclose(db, dz.float().sum(0), rtol=1e-4, atol=1e-4 * float(dz.float().abs().sum(0).max()) + 1e-6)
+                dz2, db2 = nv.linear_mask_bwd(dy, w2t, ys, p)
+                assert torch.equal(dz, dz2) and torch.equal(db, db2)
+    with pytest.raises(nv.NativeError):
+        nv.linear_relu_dropout(torch.zeros(8, 512, device=dev, dtype=torch.bfloat16),
+                               torch.zeros(128, 512, device=dev, dtype=torch.bfloat16), torch.zeros(128, device=dev), 0.0)
+
+
+def test_linked_ffn_block_matches_torch(dev):
+    """linear1 -> ReLU -> linear2 -> add -> LayerNorm through _LinearReluDropout + _LinearAddLayerNorm joined by an FFNLink
+    (the fused forward epilogue and the masked-gradient GEMM) vs the PyTorch composition: outputs and all gradients."""
+    import torch.nn.functional as F
+
+    from src.ppo.hip_ops import FFNLink, _LinearAddLayerNorm, _LinearReluDropout
+
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+    torch.manual_seed(29)
+    B, S = 300, 17  # 5100 tokens: the fused kernels engage
+    h = torch.randn(B, S, 256, device=dev).to(torch.bfloat16).requires_grad_(True)
+    x = torch.randn(B, S, 256, device=dev).requires_grad_(True)
+    w1 = (torch.randn(1024, 256, device=dev) / 16).requires_grad_(True)
+    b1 = (0.1 * torch.randn(1024, device=dev)).requires_grad_(True)
+    w2 = (torch.randn(256, 1024, device=dev) / 32).requires_grad_(True)
+    b2 = (0.1 * torch.randn(256, device=dev)).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(256, device=dev)).requires_grad_(True)
+    beta = (0.1 * torch.randn(256, device=dev)).requires_grad_(True)
+    gx, gh = torch.randn(x.shape, device=dev), torch.randn(x.shape, device=dev).to(torch.bfloat16)
+    leaves = (h, x, w1, b1, w2, b2, gamma, beta)
+    bf = lambda t: t.detach().to(torch.bfloat16)
+    link = FFNLink(0.0)
+    f = _LinearReluDropout.apply(h, w1, b1, bf(w1), bf(b1), 0.0, link)
+    x_new, hn = _LinearAddLayerNorm.apply(f, w2, b2, bf(w2), bf(b2), x, gamma, beta, 1e-5, 0.0, bf(w2).t().contiguous(), link)
+    torch.autograd.backward([x_new, hn], [gx, gh])
+    assert link.db is None and not link.masked  # consumed by the first node's backward
+    got = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    fr = torch.relu(F.linear(h, w1.to(torch.bfloat16), b1.to(torch.bfloat16)))
+    xr = x + F.linear(fr, w2.to(torch.bfloat16), b2.to(torch.bfloat16)).float()
+    hr = F.layer_norm(xr, (256,), gamma, beta, 1e-5)
+    torch.autograd.backward([xr, hr], [gx, gh.float()])
+    assert rel(f, fr) < 4e-3 and rel(x_new, xr) < 4e-3 and rel(hn, hr) < 6e-3
+    for name, g, t in zip(("h", "x", "w1", "b1", "w2", "b2", "gamma", "beta"), got, leaves):
+        assert rel(g, t.grad) < 2e-2, (name, rel(g, t.grad))
+    # with dropout: the gradient of h vanishes through dropped units -- same mask forward and backward
+    link = FFNLink(0.5)
+    f = _LinearReluDropout.apply(h, w1, b1, bf(w1), bf(b1), 0.5, link)
+    x_new, hn = _LinearAddLayerNorm.apply(f, w2, b2, bf(w2), bf(b2), x, gamma, beta, 1e-5, 0.0, bf(w2).t().contiguous(), link)
+    for t in leaves:
+        t.grad = None
+    torch.autograd.backward([x_new, hn], [gx, gh])
+    kept = (f != 0).float()
+    assert abs(kept.mean().item() / (fr != 0).float().mean().item() - 0.5) < 0.01
+    active_cols = kept.reshape(-1, 1024).sum(0) > 0
+    assert (b1.grad[~active_cols] == 0).all() and torch.isfinite(w1.grad).all() and torch.isfinite(h.grad).all()
+
+
 def test_linear_bf16_matches_torch(dev):
     """g2048_linear_bf16 (MFMA, weights streamed through LDS) vs an f32 reference: as close as hipBLASLt's bf16 GEMM,
     ragged T, all (K, N) of the update, strided inputs/weights (views), with and without bias."""
