@@ -208,9 +208,25 @@ extern "C" int64_t g2048_colsum_workspace_floats(int64_t T, int N) {
     return (int64_t)G2048_COLSUM_MAX_GROUPS * N;
 }
 
+namespace {
+inline int64_t colsum_groups(int64_t T, int n) {
+    const int rows_per_pass = CS_THREADS / (n / CS_VEC);
+    int64_t G = (T + rows_per_pass - 1) / rows_per_pass;
+    // at least ~16 rows per workgroup, at most MAX_GROUPS workgroups
+    G = (G + 15) / 16;
+    if (G > G2048_COLSUM_MAX_GROUPS) G = G2048_COLSUM_MAX_GROUPS;
+    return G < 1 ? 1 : G;
+}
+}  // namespace
+
+extern "C" int64_t g2048_colsum_partial_rows(int64_t T, int N) {
+    return (T <= 0 || N < CS_VEC || N % CS_VEC || N > CS_THREADS * CS_VEC) ? 0 : colsum_groups(T, N);
+}
+
 extern "C" int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int64_t T, int N, float *workspace, float *out,
                             void *stream) {
-    if (!x || !workspace || !out || T <= 0 || N < CS_VEC || N % CS_VEC || row_stride % CS_VEC || row_stride < N ||
+    if (!out && N > CS_THREADS * CS_VEC) return G2048_EINVAL;  // first stage only: one column tile
+    if (!x || !workspace || T <= 0 || N < CS_VEC || N % CS_VEC || row_stride % CS_VEC || row_stride < N ||
         ((uintptr_t)x & (is_bf16 ? 7 : 15)) || ((uintptr_t)workspace & 15))
         return G2048_EINVAL;
     // wider matrices are summed in column tiles of at most CS_THREADS * CS_VEC (1024) columns, each with its own slice of
@@ -220,20 +236,16 @@ extern "C" int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int6
         const int n = N - c0 < TILE_N ? N - c0 : TILE_N;
         const void *xt = is_bf16 ? (const void *)((const uint16_t *)x + c0) : (const void *)((const float *)x + c0);
         float *ws = workspace + (int64_t)G2048_COLSUM_MAX_GROUPS * c0;
-        const int rows_per_pass = CS_THREADS / (n / CS_VEC);
-        int64_t G = (T + rows_per_pass - 1) / rows_per_pass;
-        // at least ~16 rows per workgroup, at most MAX_GROUPS workgroups
-        G = (G + 15) / 16;
-        if (G > G2048_COLSUM_MAX_GROUPS) G = G2048_COLSUM_MAX_GROUPS;
-        if (G < 1) G = 1;
+        const int64_t G = colsum_groups(T, n);
         if (is_bf16)
             hipLaunchKernelGGL(k_colsum_partial<true>, dim3((unsigned)G), dim3(CS_THREADS), 0, (hipStream_t)stream, xt, row_stride, T,
                                n, ws);
         else
             hipLaunchKernelGGL(k_colsum_partial<false>, dim3((unsigned)G), dim3(CS_THREADS), 0, (hipStream_t)stream, xt, row_stride, T,
                                n, ws);
-        hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((n + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_SLICES), 0,
-                           (hipStream_t)stream, ws, (int)G, n, out + c0);
+        if (out)
+            hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((n + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_SLICES), 0,
+                               (hipStream_t)stream, ws, (int)G, n, out + c0);
     }
     return done();
 }
@@ -245,7 +257,7 @@ extern "C" int64_t g2048_add_ln_bwd_workspace_floats(int64_t T) {
 extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
                                 const float *rstd, const float *gamma, float *dx, void *da, float *dparams, float *workspace,
                                 int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream) {
-    if (!x_norm || !g_h || !mean || !rstd || !gamma || !dx || !dparams || !workspace || T <= 0 || (x_row_stride & 3) ||
+    if (!x_norm || !g_h || !mean || !rstd || !gamma || !dx || !workspace || T <= 0 || (x_row_stride & 3) ||
         !(p_drop >= 0.f && p_drop < 1.f) || (((uintptr_t)x_norm | (uintptr_t)g_x | (uintptr_t)dx | (uintptr_t)gamma) & 15) ||
         (((uintptr_t)g_h | (uintptr_t)da) & 7))
         return G2048_EINVAL;
@@ -254,8 +266,9 @@ extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const
     hipLaunchKernelGGL(k_add_ln_bwd, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream, x_norm, x_row_stride, g_x,
                        (const uint16_t *)g_h, mean, rstd, gamma, dx, (uint16_t *)da, workspace, T, 1.0f / (1.0f - p_drop), thr,
                        (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
-    hipLaunchKernelGGL(k_colsum_final, dim3(3 * D / CF_COLS), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream, workspace, (int)blocks, 3 * D,
-                       dparams);
+    if (dparams)
+        hipLaunchKernelGGL(k_colsum_final, dim3(3 * D / CF_COLS), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream, workspace, (int)blocks,
+                           3 * D, dparams);
     return done();
 }
 
@@ -348,14 +361,15 @@ extern "C" int64_t g2048_relu_dropout_bwd_workspace_floats(int64_t T, int F) {
 
 extern "C" int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, float *workspace, int64_t T, int F,
                                       float p_drop, void *stream) {
-    if (!dy || !y || !dx || !dbias || !workspace || !rd_shape_ok(T, F) || !(p_drop >= 0.f && p_drop < 1.f) ||
+    if (!dy || !y || !dx || !workspace || !rd_shape_ok(T, F) || !(p_drop >= 0.f && p_drop < 1.f) ||
         (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)workspace) & 15))
         return G2048_EINVAL;
     const int64_t blocks = (T + RD_ROWS_PER_BLOCK - 1) / RD_ROWS_PER_BLOCK;
     hipLaunchKernelGGL(k_relu_dropout_bwd, dim3((unsigned)blocks), dim3(RD_THREADS), 0, (hipStream_t)stream, (const uint4 *)dy,
                        (const uint4 *)y, (uint4 *)dx, workspace, T, F, 1.0f / (1.0f - p_drop));
-    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((F + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream, workspace, (int)blocks, F,
-                       dbias);
+    if (dbias)
+        hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((F + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream,
+                           workspace, (int)blocks, F, dbias);
     return done();
 }
 

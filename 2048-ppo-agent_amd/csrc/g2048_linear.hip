@@ -322,11 +322,19 @@ extern "C" int64_t g2048_linear_mask_bwd_workspace_floats(int64_t T, int N) {
     return (T <= 0 || N < NS || N % NS) ? 0 : (int64_t)512 * N;  // at most 512 / (N / 128) workgroup rows of N partial sums
 }
 
+extern "C" int64_t g2048_linear_mask_bwd_partial_rows(int64_t T, int N) {
+    if (T <= 0 || N < NS || N % NS) return 0;
+    int64_t groups = 512 / (N / NS);
+    const int64_t n_tiles = (T + TOK - 1) / TOK;
+    if (groups < 1) groups = 1;
+    return groups > n_tiles ? n_tiles : groups;
+}
+
 extern "C" int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const void *weight_t, int64_t ldw, const void *y_saved,
                                           int64_t ldm, void *dz, int64_t lddz, float *dbias, float *workspace, int64_t T, int K,
                                           int N, float p_drop, void *stream) {
     if (!operands_ok(dy, lddy, weight_t, ldw, dz, lddz, T, K, N, nullptr) || K > NBUF * KC || !y_saved || ldm < N || (ldm & 7) ||
-        !dbias || !workspace || (((uintptr_t)y_saved | (uintptr_t)workspace) & 15) || !(p_drop >= 0.f && p_drop < 1.f))
+        !workspace || (((uintptr_t)y_saved | (uintptr_t)workspace) & 15) || !(p_drop >= 0.f && p_drop < 1.f))
         return G2048_EINVAL;
     Epi E{};
     E.inv_keep = 1.0f / (1.0f - p_drop);
@@ -337,7 +345,7 @@ extern "C" int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const vo
     int groups = 0;
     const int rc = launch_stationary<false, EPI_MASK_COLSUM>((const __bf16 *)dy, lddy, (const __bf16 *)weight_t, ldw, nullptr, (__bf16 *)dz,
                                                              lddz, T, K, N, E, &groups, (hipStream_t)stream);
-    if (rc) return rc;
+    if (rc || !dbias) return rc;  // dbias NULL: the partial rows stay in the workspace for g2048_reduce_jobs
     hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream,
                        workspace, groups, N, dbias);
     const hipError_t e = hipGetLastError();

@@ -1,4 +1,4 @@
-// The optimiser step of the PPO update in two launches: gradient-norm clipping, GradScaler bookkeeping and AdamW over all
+// The optimiser step of the PPO update in three launches: gradient-norm clipping, GradScaler bookkeeping and AdamW over all
 // parameters at once (reference: src/ppo/ppo_trainer.py:413-434 - scaler.unscale_, clip_grad_norm_, scaler.step(AdamW),
 // scaler.update - which PyTorch runs as ~12 multi-tensor launches per minibatch, 0.25 ms of a 3.2 ms minibatch).
 //
@@ -9,8 +9,9 @@
 //   k_opt_adamw  : every workgroup adds the partials in the same order -> total norm, found_inf, clip factor; then
 //                  g' = (g * inv_scale) * clip;  p -= lr*wd*p;  m = lerp(m, g', 1-b1);  v = b2*v + (1-b2)*g'^2;
 //                  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)                      (torch's fused AdamW arithmetic)
-//                  unless found_inf; the LAST workgroup to finish advances the step count and the scaler
-//                  (scale *= backoff on inf, *= growth after growth_interval clean steps), as scaler.update() does.
+//                  unless found_inf
+//   k_opt_finish : one workgroup advances the step counts and the scaler (scale *= backoff on inf, *= growth after
+//                  growth_interval clean steps), as scaler.update() does.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,9 +35,37 @@ __device__ __forceinline__ float block_sum(float v, float *lds) {
     return s;
 }
 
+struct StepArgs {
+    g2048_opt_group groups[G2048_OPT_MAX_GROUPS];
+    float max_grad_norm;  // <= 0: no clipping
+    float growth, backoff;
+    int growth_interval;
+};
+
+// per-group constants of one step, derived once (by workgroup 0 of k_opt_sqnorm) from the f64 hyper-parameters and the step
+// count: the two f64 pow calls of the bias corrections cost microseconds and must not sit in every workgroup of the update
+struct Derived { float step_size, inv_bc2_sqrt, lr_wd, w1, b2, w2, eps, pad; };
+
 __global__ void __launch_bounds__(OPT_THREADS)
-k_opt_sqnorm(const g2048_opt_chunk *__restrict__ chunks, const float *__restrict__ grads, float *__restrict__ partial) {
+k_opt_sqnorm(const g2048_opt_chunk *__restrict__ chunks, const float *__restrict__ grads, float *__restrict__ partial, StepArgs A,
+             int n_groups, const float *__restrict__ steps, Derived *__restrict__ derived) {
     __shared__ float lds[OPT_THREADS / 64];
+    if (blockIdx.x == 0 && threadIdx.x < n_groups) {
+        const g2048_opt_group G = A.groups[threadIdx.x];
+        const double t = (double)steps[0] + 1.0;
+        const double bc1 = 1.0 - pow(G.beta1, t), bc2 = 1.0 - pow(G.beta2, t);
+        Derived d;
+        // hyper-parameters arrive as f64 (what torch.optim holds) and are rounded once, after the f64 arithmetic on them
+        d.step_size = (float)(G.lr / bc1);
+        d.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+        d.lr_wd = (float)(G.lr * G.weight_decay);
+        d.w1 = (float)(1.0 - G.beta1);
+        d.b2 = (float)G.beta2;
+        d.w2 = (float)(1.0 - G.beta2);
+        d.eps = (float)G.eps;
+        d.pad = 0.f;
+        derived[threadIdx.x] = d;
+    }
     const g2048_opt_chunk c = chunks[blockIdx.x];
     const float *g = grads + c.offset;
     float s = 0.f;
@@ -52,13 +81,6 @@ k_opt_sqnorm(const g2048_opt_chunk *__restrict__ chunks, const float *__restrict
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
-struct StepArgs {
-    g2048_opt_group groups[G2048_OPT_MAX_GROUPS];
-    float max_grad_norm;  // <= 0: no clipping
-    float growth, backoff;
-    int growth_interval;
-};
-
 __device__ __forceinline__ void adamw1(float &p, float g, float &m, float &v, float lr_wd, float w1, float b2, float w2,
                                        float step_size, float inv_bc2_sqrt, float eps) {
     p -= lr_wd * p;
@@ -71,42 +93,34 @@ __device__ __forceinline__ void adamw1(float &p, float g, float &m, float &v, fl
 
 __global__ void __launch_bounds__(OPT_THREADS)
 k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const float *__restrict__ grads, float *__restrict__ exp_avg,
-            float *__restrict__ exp_avg_sq, const float *__restrict__ partial, StepArgs A, float *__restrict__ steps, int n_steps,
-            float *__restrict__ scale, int32_t *__restrict__ growth_tracker, float *__restrict__ info,
-            uint32_t *__restrict__ counter) {
+            float *__restrict__ exp_avg_sq, const float *__restrict__ partial, const Derived *__restrict__ derived, float max_grad_norm,
+            const float *__restrict__ scale) {
     __shared__ float lds[OPT_THREADS / 64];
-    __shared__ float sh[4];
-    __shared__ int is_last;
+    __shared__ float sh[2];
     // total of the partials, identical in every workgroup (fixed order: strided per thread, then the block tree)
     float s = 0.f;
     for (int i = threadIdx.x; i < n_chunks; i += OPT_THREADS) s += partial[i];
     const float total = block_sum(s, lds);
     const g2048_opt_chunk c = chunks[blockIdx.x];
-    const g2048_opt_group G = A.groups[c.group];
+    const Derived G = derived[c.group];
     if (threadIdx.x == 0) {
         const float sc = scale ? *scale : 1.f;
         const float inv_scale = (float)(1.0 / (double)sc);  // scaler.unscale_: grads *= scale.double().reciprocal().float()
         // the norm of the unscaled gradients; non-finite anywhere makes the total non-finite
         const float norm = sqrtf(total) * inv_scale;
         float clip = 1.f;
-        if (A.max_grad_norm > 0.f) {
-            clip = A.max_grad_norm / (norm + 1e-6f);  // torch.nn.utils.clip_grad_norm_
+        if (max_grad_norm > 0.f) {
+            clip = max_grad_norm / (norm + 1e-6f);  // torch.nn.utils.clip_grad_norm_
             if (clip > 1.f) clip = 1.f;
         }
-        const float t = steps[0] + 1.f;
-        const double bc1 = 1.0 - pow(G.beta1, (double)t), bc2 = 1.0 - pow(G.beta2, (double)t);
         sh[0] = inv_scale;
         sh[1] = clip;
-        sh[2] = (float)(G.lr / bc1);
-        sh[3] = (float)(1.0 / sqrt(bc2));
     }
     __syncthreads();
     const bool found_inf = scale != nullptr && !(fabsf(total) <= 3.4028234664e38f);  // inf or nan; without a scaler torch steps anyway
     if (!found_inf) {
-        const float inv_scale = sh[0], clip = sh[1], step_size = sh[2], inv_bc2_sqrt = sh[3];
-        // hyper-parameters arrive as f64 (what torch.optim holds) and are rounded once, after the f64 arithmetic on them
-        const float lr_wd = (float)(G.lr * G.weight_decay), w1 = (float)(1.0 - G.beta1), b2 = (float)G.beta2,
-                    w2 = (float)(1.0 - G.beta2), eps = (float)G.eps;
+        const float inv_scale = sh[0], clip = sh[1], step_size = G.step_size, inv_bc2_sqrt = G.inv_bc2_sqrt;
+        const float lr_wd = G.lr_wd, w1 = G.w1, b2 = G.b2, w2 = G.w2, eps = G.eps;
         float *p = c.param;
         const float *g = grads + c.offset;
         float *m = exp_avg + c.offset, *v = exp_avg_sq + c.offset;
@@ -131,29 +145,35 @@ k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const floa
             }
         }
     }
-    // bookkeeping by the last workgroup to get here: every other one has already read the step count and the scale
-    if (threadIdx.x == 0) {
-        __threadfence();
-        is_last = atomicAdd(counter, 1u) == (uint32_t)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!is_last) return;
+}
+
+// Bookkeeping after the update, one workgroup: the same total (same order) -> found_inf; step counts, scaler state, info.
+// A launch of its own instead of a "last workgroup done" counter: a device-scope release fence per workgroup makes every
+// one of them write back its XCD's L2 (measured: 114 us for the update kernel instead of 20).
+__global__ void __launch_bounds__(OPT_THREADS)
+k_opt_finish(const float *__restrict__ partial, int n_chunks, float growth, float backoff, int growth_interval, float *__restrict__ steps,
+             int n_steps, float *__restrict__ scale, int32_t *__restrict__ growth_tracker, float *__restrict__ info) {
+    __shared__ float lds[OPT_THREADS / 64];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_chunks; i += OPT_THREADS) s += partial[i];
+    const float total = block_sum(s, lds);
+    const bool found_inf = scale != nullptr && !(fabsf(total) <= 3.4028234664e38f);
     if (!found_inf)
         for (int i = threadIdx.x; i < n_steps; i += OPT_THREADS) steps[i] += 1.f;  // one count per parameter, as torch keeps them
     if (threadIdx.x == 0) {
-        *counter = 0;
         if (info) {
-            info[0] = sqrtf(total) * sh[0];  // total gradient norm before clipping (what clip_grad_norm_ returns)
+            const float sc = scale ? *scale : 1.f;
+            info[0] = sqrtf(total) * (float)(1.0 / (double)sc);  // gradient norm before clipping (what clip_grad_norm_ returns)
             info[1] = found_inf ? 1.f : 0.f;
         }
         if (scale) {
             if (found_inf) {
-                *scale *= A.backoff;
+                *scale *= backoff;
                 *growth_tracker = 0;
             } else {
                 const int32_t ok = *growth_tracker + 1;
-                if (ok == A.growth_interval) {
-                    *scale *= A.growth;
+                if (ok == growth_interval) {
+                    *scale *= growth;
                     *growth_tracker = 0;
                 } else {
                     *growth_tracker = ok;
@@ -175,17 +195,19 @@ extern "C" int g2048_opt_step(const g2048_opt_chunk *chunks, int n_chunks, const
         return G2048_EINVAL;
     StepArgs A;
     for (int i = 0; i < G2048_OPT_MAX_GROUPS; ++i) A.groups[i] = groups[i < n_groups ? i : 0];
-    A.max_grad_norm = max_grad_norm;
-    A.growth = growth; A.backoff = backoff; A.growth_interval = growth_interval;
-    // workspace: [n_chunks] partial sums, then (16-byte aligned) the completion counter, which the caller zeroed once and the
-    // kernel leaves at zero
+    // workspace: [n_chunks] partial sums, then the per-group constants
     float *partial = workspace;
-    uint32_t *counter = reinterpret_cast<uint32_t *>(workspace + ((n_chunks + 3) & ~3));
-    hipLaunchKernelGGL(k_opt_sqnorm, dim3((unsigned)n_chunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, chunks, grads, partial);
+    Derived *derived = reinterpret_cast<Derived *>(workspace + ((n_chunks + 3) & ~3));
+    hipLaunchKernelGGL(k_opt_sqnorm, dim3((unsigned)n_chunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, chunks, grads, partial, A,
+                       n_groups, steps, derived);
     hipLaunchKernelGGL(k_opt_adamw, dim3((unsigned)n_chunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, chunks, n_chunks, grads,
-                       exp_avg, exp_avg_sq, partial, A, steps, n_steps, scale, growth_tracker, info, counter);
+                       exp_avg, exp_avg_sq, partial, derived, max_grad_norm, scale);
+    hipLaunchKernelGGL(k_opt_finish, dim3(1), dim3(OPT_THREADS), 0, (hipStream_t)stream, partial, n_chunks, growth, backoff,
+                       growth_interval, steps, n_steps, scale, growth_tracker, info);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }
 
-extern "C" int64_t g2048_opt_workspace_floats(int n_chunks) { return n_chunks <= 0 ? 0 : (int64_t)((n_chunks + 3) & ~3) + 4; }
+extern "C" int64_t g2048_opt_workspace_floats(int n_chunks) {
+    return n_chunks <= 0 ? 0 : (int64_t)((n_chunks + 3) & ~3) + G2048_OPT_MAX_GROUPS * (int64_t)(sizeof(Derived) / sizeof(float));
+}

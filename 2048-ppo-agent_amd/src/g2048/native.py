@@ -64,6 +64,9 @@ SIGNATURES = {
     "g2048_gather_minibatch": [_vp, _i64, _i64] + [_vp] * 13,
     "g2048_colsum_workspace_floats": [_i64, _i32],
     "g2048_colsum": [_vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp],
+    "g2048_colsum_partial_rows": [_i64, _i32],
+    "g2048_linear_mask_bwd_partial_rows": [_i64, _i32],
+    "g2048_reduce_jobs": [_vp, _i32, _vp],
     "g2048_add_ln_bwd_workspace_floats": [_i64],
     "g2048_add_ln_bwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp,
                          _vp],
@@ -95,7 +98,7 @@ def load() -> C.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
-            fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_workspace_bytes")) else C.c_int
+            fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_workspace_bytes", "_partial_rows")) else C.c_int
         if lib.g2048_abi_version() != 2:
             raise NativeError("libg2048.so ABI version mismatch")
         _lib = lib
@@ -346,15 +349,17 @@ def add_ln_fwd(x_ptr: int, x_row_stride: int, a, gamma, beta, x_new, h, mean, rs
 
 def add_ln_bwd(xn_ptr: int, x_row_stride: int, g_x, g_h, mean, rstd, gamma, dx, da, dparams, T: int,
                p_drop: float, seed: int, seed_state: int = 0):
-    """dparams f32 [3, 256]: dgamma, dbeta, column sums of da."""
+    """dparams f32 [3, 256]: dgamma, dbeta, column sums of da.  dparams None: first stage only -> the workspace, f32
+    [rows, 768] partial sums (for ``reduce_jobs``)."""
     bf = torch.bfloat16
     ws = torch.empty(load().g2048_add_ln_bwd_workspace_floats(T), dtype=f32, device=dx.device)
     _check(load().g2048_add_ln_bwd(xn_ptr, int(x_row_stride), _dev(g_x, f32, 256 * T, "g_x", optional=True),
                                    _dev(g_h, bf, 256 * T, "g_h"), _dev(mean, f32, T, "mean"), _dev(rstd, f32, T, "rstd"),
                                    _dev(gamma, f32, 256, "gamma"), _dev(dx, f32, 256 * T, "dx"),
-                                   _dev(da, bf, 256 * T, "da", optional=True), _dev(dparams, f32, 768, "dparams"),
+                                   _dev(da, bf, 256 * T, "da", optional=True), _dev(dparams, f32, 768, "dparams", optional=True),
                                    ws.data_ptr(), T, float(p_drop), int(seed), seed_state or None, _stream()),
            "g2048_add_ln_bwd")
+    return ws.view(-1, 768) if dparams is None else None
 
 
 def relu_dropout_fwd(x, y, p_drop: float, seed: int, seed_state: int = 0):
@@ -366,13 +371,15 @@ def relu_dropout_fwd(x, y, p_drop: float, seed: int, seed_state: int = 0):
 
 
 def relu_dropout_bwd(dy, y, dx, dbias, p_drop: float):
+    """dbias None: first stage only -> the workspace, f32 [rows, F] partial sums (for ``reduce_jobs``)."""
     bf = torch.bfloat16
     F = y.shape[-1]
     T = y.numel() // F
     ws = torch.empty(load().g2048_relu_dropout_bwd_workspace_floats(T, F), dtype=f32, device=y.device)
     _check(load().g2048_relu_dropout_bwd(_dev(dy, bf, T * F, "dy"), _dev(y, bf, T * F, "y"), _dev(dx, bf, T * F, "dx"),
-                                         _dev(dbias, f32, F, "dbias"), ws.data_ptr(), T, F, float(p_drop), _stream()),
-           "g2048_relu_dropout_bwd")
+                                         _dev(dbias, f32, F, "dbias", optional=True), ws.data_ptr(), T, F, float(p_drop),
+                                         _stream()), "g2048_relu_dropout_bwd")
+    return ws.view(-1, F) if dbias is None else None
 
 
 COLSUM_MAX_GROUPS = 512
@@ -390,6 +397,41 @@ def colsum(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     _check(load().g2048_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), x.stride(0), T, N, ws.data_ptr(),
                                _dev(out, f32, N, "out"), _stream()), "g2048_colsum")
     return out
+
+
+def colsum_partial(x: torch.Tensor) -> torch.Tensor:
+    """First stage of ``colsum`` only -> f32 [rows, N] partial sums (for ``reduce_jobs``); N <= 1024."""
+    if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (torch.bfloat16, f32):
+        raise NativeError(f"colsum_partial: expected a 2-D bf16/f32 device tensor with contiguous rows, got {x.dtype} "
+                          f"{tuple(x.shape)} strides {x.stride()}")
+    T, N = x.shape
+    rows = load().g2048_colsum_partial_rows(T, N)
+    if rows <= 0:
+        raise NativeError(f"colsum_partial: unsupported shape {tuple(x.shape)}")
+    ws = torch.empty(load().g2048_colsum_workspace_floats(T, N), dtype=f32, device=x.device)
+    _check(load().g2048_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), x.stride(0), T, N, ws.data_ptr(), None, _stream()),
+           "g2048_colsum")
+    return ws[:rows * N].view(rows, N)
+
+
+class ReduceJob(C.Structure):  # g2048_reduce_job
+    _fields_ = [("src", _vp), ("dst", _vp), ("part_stride", _i64), ("n", C.c_int32), ("parts", C.c_int32),
+                ("src_bf16", C.c_int32), ("reserved", C.c_int32)]
+
+
+def reduce_jobs(jobs):
+    """jobs: list of (src tensor whose first element is part 0 / column 0, dst f32 tensor, part_stride, n, parts):
+    dst[c] = sum_p src[p * part_stride + c]; all of them in one launch (per 64)."""
+    if not jobs:
+        return
+    recs = []
+    for src, dst, stride, n, parts in jobs:
+        if not src.is_cuda or src.dtype not in (torch.bfloat16, f32) or not dst.is_cuda or dst.dtype != f32 \
+                or not dst.is_contiguous() or dst.numel() < n:
+            raise NativeError(f"reduce_jobs: bad job {src.dtype} {tuple(src.shape)} -> {dst.dtype} {tuple(dst.shape)} (n={n})")
+        recs.append(ReduceJob(src.data_ptr(), dst.data_ptr(), int(stride), int(n), int(parts), int(src.dtype == torch.bfloat16), 0))
+    arr = (ReduceJob * len(recs))(*recs)
+    _check(load().g2048_reduce_jobs(C.cast(arr, _vp), len(recs), _stream()), "g2048_reduce_jobs")
 
 
 def ppo_loss(logits, values, actions, mask_bits, old_logp, adv, ret, clip_eps: float, c_value: float, c_entropy: float):
@@ -448,9 +490,9 @@ def linear_relu_dropout(x2: torch.Tensor, weight: torch.Tensor, bias_f32: torch.
     return out
 
 
-def linear_mask_bwd(dy2: torch.Tensor, weight_t: torch.Tensor, y_saved2: torch.Tensor, p_drop: float):
+def linear_mask_bwd(dy2: torch.Tensor, weight_t: torch.Tensor, y_saved2: torch.Tensor, p_drop: float, final: bool = True):
     """-> (dz bf16 [T, N], dbias f32 [N]): dz = (dy2 @ weight_t^T) / (1 - p) where y_saved2 != 0; see
-    g2048_linear_mask_bwd_bf16."""
+    g2048_linear_mask_bwd_bf16.  ``final`` False: (dz, partial sums f32 [rows, N]) for ``reduce_jobs``."""
     if not linear_ok(dy2, weight_t) or dy2.shape[1] > 256:
         raise NativeError(f"linear_mask_bwd: unsupported operands {tuple(dy2.shape)} {dy2.dtype} x {tuple(weight_t.shape)}")
     T, K = dy2.shape
@@ -459,12 +501,16 @@ def linear_mask_bwd(dy2: torch.Tensor, weight_t: torch.Tensor, y_saved2: torch.T
             or y_saved2.stride(0) % 8 or y_saved2.data_ptr() % 16:
         raise NativeError(f"linear_mask_bwd: y_saved {tuple(y_saved2.shape)} {y_saved2.dtype} does not match [{T}, {N}] bf16")
     dz = torch.empty((T, N), dtype=torch.bfloat16, device=dy2.device)
-    db = torch.empty(N, dtype=f32, device=dy2.device)
+    db = torch.empty(N, dtype=f32, device=dy2.device) if final else None
     ws = torch.empty(load().g2048_linear_mask_bwd_workspace_floats(T, N), dtype=f32, device=dy2.device)
     _check(load().g2048_linear_mask_bwd_bf16(dy2.data_ptr(), dy2.stride(0), weight_t.data_ptr(), weight_t.stride(0),
-                                             y_saved2.data_ptr(), y_saved2.stride(0), dz.data_ptr(), N, db.data_ptr(),
-                                             ws.data_ptr(), T, K, N, float(p_drop), _stream()), "g2048_linear_mask_bwd_bf16")
-    return dz, db
+                                             y_saved2.data_ptr(), y_saved2.stride(0), dz.data_ptr(), N,
+                                             db.data_ptr() if final else None, ws.data_ptr(), T, K, N, float(p_drop), _stream()),
+           "g2048_linear_mask_bwd_bf16")
+    if final:
+        return dz, db
+    rows = load().g2048_linear_mask_bwd_partial_rows(T, N)
+    return dz, ws[:rows * N].view(rows, N)
 
 
 def embed_fwd(boards, wt, pe, cls, x0, p_drop: float = 0.0, seed: int = 0, seed_state: int = 0):

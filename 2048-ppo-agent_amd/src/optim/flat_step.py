@@ -1,4 +1,4 @@
-"""The PPO update's optimiser step in two HIP launches (``g2048_opt_step``, csrc/g2048_optim.hip).
+"""The PPO update's optimiser step in three HIP launches (``g2048_opt_step``, csrc/g2048_optim.hip).
 
 The reference runs ``scaler.unscale_(opt); clip_grad_norm_(params, max_norm); scaler.step(opt); scaler.update()``
 (src/ppo/ppo_trainer.py:413-434) with ``opt = torch.optim.AdamW`` over two weight-decay groups
@@ -6,7 +6,7 @@ The reference runs ``scaler.unscale_(opt); clip_grad_norm_(params, max_norm); sc
 ``FlatAdamWStep`` keeps the SAME ``torch.optim.AdamW`` object (its ``param_groups`` drive the LR schedule, its
 ``state_dict()`` is what checkpoints store) but owns the storage behind it: gradients, ``exp_avg`` and ``exp_avg_sq`` of all
 parameters live in three flat f32 buffers, ``optimizer.state[p]`` holds views into them, and ``step()`` is one call into the
-kernel pair.  The flat gradient buffer doubles as the all-reduce bucket of a multi-GPU run.
+kernel sequence.  The flat gradient buffer doubles as the all-reduce bucket of a multi-GPU run.
 """
 from __future__ import annotations
 

@@ -61,6 +61,119 @@ class Bf16Shadow:
         return self.views
 
 
+class _SideWork:
+    """Weight and bias gradients on a second HIP stream.
+
+    In the backward of a Linear only the input gradient is on the critical path; dW (a split-K GEMM plus its reduction)
+    and db (column sums) feed nothing but the optimiser.  Inside ``weight_grads_on_side_stream()`` the autograd nodes of this
+    module enqueue that work on a side stream that forks from the backward stream at the point of the call and is joined
+    when the context exits; captured in a hipGraph this becomes a parallel branch, so the many small launches of the
+    weight-gradient path fill the gaps of the (bandwidth-bound) activation-gradient chain instead of extending it.
+    Operands are kept alive until the join (the caching allocator knows nothing of the side stream's reads)."""
+
+    enabled = False
+    streams, pending, used = {}, {}, set()
+
+    @classmethod
+    def run(cls, keep, fn):
+        if not cls.enabled:
+            return fn()
+        dev = keep[0].device
+        side = cls.streams.get(dev)
+        if side is None:
+            side = cls.streams[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            out = fn()
+        cls.pending.setdefault(dev, []).extend(keep)
+        cls.used.add(dev)
+        return out
+
+    @classmethod
+    def join(cls):
+        for dev in list(cls.used):
+            torch.cuda.current_stream(dev).wait_stream(cls.streams[dev])
+        cls.used.clear()
+        cls.pending.clear()
+
+
+class weight_grads_on_side_stream:
+    """Context manager around ``loss.backward()``: see ``_SideWork``.  Gradients of weights and biases are complete (on
+    the current stream) when the context exits."""
+
+    def __init__(self, enabled: bool = True):
+        self.on = enabled
+
+    def __enter__(self):
+        self.prev = _SideWork.enabled
+        _SideWork.enabled = bool(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        _SideWork.enabled = self.prev
+        _SideWork.join()
+        return False
+
+
+class GradSink:
+    """All second-stage gradient reductions of one backward pass in ONE launch (``g2048_reduce_jobs``).
+
+    ``targets`` maps ``id(parameter)`` to the f32 buffer its gradient must end up in (a view of the optimiser's flat
+    gradient buffer).  While a sink is active (``with grad_sink(sink): loss.backward()``) the autograd nodes of this module
+    do not reduce their weight / bias / LayerNorm gradients themselves: they leave the partials where the first stage put
+    them (the 16 split-K slices of a weight gradient, the per-workgroup column sums of a bias gradient), register a job
+    and return None for that input; ``flush()`` then sums every job straight into its target.  That replaces ~50
+    launches per minibatch (at::sum per weight, k_colsum_final per bias, bf16 -> f32 copies) by one.
+    ``written`` holds the ids of the parameters whose gradient the sink produced (autograd never saw them)."""
+
+    active = None
+
+    def __init__(self, targets: dict):
+        self.targets, self.jobs, self.written = targets, [], set()
+
+    def takes(self, *params) -> bool:
+        return all(p is not None and id(p) in self.targets for p in params)
+
+    def add(self, param, src: torch.Tensor, part_stride: int, n: int, parts: int, dst_offset: int = 0):
+        """grad(param).flatten()[dst_offset : dst_offset + n] = sum over parts of src (src's first element = part 0,
+        column 0; the tensor is kept alive until ``flush``)."""
+        dst = self.targets[id(param)].view(-1)[dst_offset:dst_offset + n]
+        self.jobs.append((src, dst, part_stride, n, parts))
+        self.written.add(id(param))
+
+    def flush(self):
+        from ..g2048 import native as nv
+
+        nv.reduce_jobs(self.jobs)
+        self.jobs = []
+
+
+class grad_sink:
+    """``with grad_sink(sink): loss.backward()`` -- activates ``sink`` (None: no-op) and flushes it on exit."""
+
+    def __init__(self, sink):
+        self.sink = sink
+
+    def __enter__(self):
+        self.prev, GradSink.active = GradSink.active, self.sink
+        return self.sink
+
+    def __exit__(self, exc_type, *exc):
+        GradSink.active = self.prev
+        if self.sink is not None and exc_type is None:
+            self.sink.flush()
+        return False
+
+
+def _sink_for(*params):
+    """The active sink if it takes the gradients of all ``params`` (None entries = absent parameters are ignored)."""
+    sink = GradSink.active
+    if sink is None:
+        return None
+    ps = [p for p in params if p is not None]
+    return sink if ps and sink.takes(*ps) else None
+
+
 def _sum_f32(t: torch.Tensor, dim: int = 0) -> torch.Tensor:
     return torch.sum(t, dim, dtype=torch.float32)
 
@@ -126,10 +239,44 @@ class FFNLink:
     bias gradient (``g2048_linear_mask_bwd_bf16``) and leaves both here for the backward of the first, which then has
     nothing left to launch for the activation."""
 
-    __slots__ = ("p_drop", "db", "masked")
+    __slots__ = ("p_drop", "db", "masked", "bias_param", "db_sunk")
 
     def __init__(self, p_drop: float):
         self.p_drop, self.db, self.masked = float(p_drop), None, False
+        self.bias_param, self.db_sunk = None, False  # linear1's bias; True when a GradSink took its gradient
+
+
+def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """The first stage of ``_dweight``: bf16 [parts, out, in] whose sum over parts is dW (parts = 16 split-K slices for a
+    long token axis, else 1)."""
+    T, S = x2.shape[0], _LinearSplitK.SLICES
+    if T % S == 0 and T // S >= 1024:
+        return torch.bmm(dy2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1))
+    return (dy2.t() @ x2).unsqueeze(0)
+
+
+def _sink_weight(sink, param, dy2, x2, dst_offset: int = 0):
+    parts = _dweight_parts(dy2, x2)
+    n = parts.shape[1] * parts.shape[2]
+    sink.add(param, parts, n, n, parts.shape[0], dst_offset)
+
+
+def _colsum_sinkable(t: torch.Tensor) -> bool:
+    N = t.shape[-1]
+    return (t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and N % 4 == 0 and N <= 1024 and t.stride(0) % 4 == 0
+            and t.dtype in (torch.bfloat16, torch.float32) and t.data_ptr() % 16 == 0)
+
+
+def _sink_bias(sink, param, dy2, dst_offset: int = 0):
+    """Bias gradient = column sums of dy2, second stage left to the sink (first stage: g2048_colsum's partial kernel)."""
+    from ..g2048 import native as nv
+
+    N = dy2.shape[-1]
+    if _colsum_sinkable(dy2):
+        ws = nv.colsum_partial(dy2)
+        sink.add(param, ws, N, N, ws.shape[0], dst_offset)
+    else:  # widths the partial kernel does not take: a finished column sum, copied into place by the sink
+        sink.add(param, _colsum(dy2).contiguous(), N, N, 1, dst_offset)
 
 
 def _dweight(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
@@ -161,6 +308,7 @@ class _LinearSplitK(torch.autograd.Function):
             y = F.linear(xb, wb, bb)
         ctx.save_for_backward(xb, wb)
         ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -171,8 +319,15 @@ class _LinearSplitK(torch.autograd.Function):
             dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16)
             x2 = xb.reshape(-1, xb.shape[-1])
             dx = (dy2 @ wb).view(xb.shape).to(x_dtype) if ctx.needs_input_grad[0] else None
-            dw = _dweight(dy2, x2).to(w_dtype)
-            db = None if b_dtype is None else _colsum(dy2).to(b_dtype)
+            weight, bias = ctx.params
+            sink = _sink_for(weight, bias) if w_dtype == torch.float32 and b_dtype in (None, torch.float32) else None
+            if sink is not None:
+                _sink_weight(sink, weight, dy2, x2)
+                if bias is not None:
+                    _sink_bias(sink, bias, dy2)
+                return dx, None, None, None, None
+            dw, db = _SideWork.run((dy2, x2), lambda: (_dweight(dy2, x2).to(w_dtype),
+                                                       None if b_dtype is None else _colsum(dy2).to(b_dtype)))
         return dx, dw, db, None, None
 
 
@@ -190,6 +345,7 @@ class _InProjCls(torch.autograd.Function):
         q = F.linear(h_cls, wb[:D], bb[:D]).view(B, 1, D)
         kv = F.linear(h, wb[D:], bb[D:])
         ctx.save_for_backward(h, h_cls, wb)
+        ctx.params = (weight, bias)
         return q, kv
 
     @staticmethod
@@ -199,12 +355,25 @@ class _InProjCls(torch.autograd.Function):
         dq2, dkv2 = dq.reshape(B, D).contiguous(), dkv.reshape(B * S, 2 * D).contiguous()
         dh = (dkv2 @ wb[D:]).view(B, S, D)
         dh[:, 0] += dq2 @ wb[:D]
-        dw = torch.empty((3 * D, D), dtype=torch.float32, device=h.device)
-        dw[:D] = dq2.t() @ h_cls
-        dw[D:] = _dweight(dkv2, h.view(B * S, D))
-        db = torch.empty(3 * D, dtype=torch.float32, device=h.device)
-        _colsum(dq2, db[:D])
-        _colsum(dkv2, db[D:])
+        weight, bias = ctx.params
+        sink = _sink_for(weight, bias)
+        if sink is not None:  # the four pieces land in their slices of the in_proj gradients
+            _sink_weight(sink, weight, dq2, h_cls, 0)
+            _sink_weight(sink, weight, dkv2, h.view(B * S, D), D * D)
+            _sink_bias(sink, bias, dq2, 0)
+            _sink_bias(sink, bias, dkv2, D)
+            return dh, None, None, None, None
+
+        def weight_grads():
+            dw = torch.empty((3 * D, D), dtype=torch.float32, device=h.device)
+            dw[:D] = dq2.t() @ h_cls
+            dw[D:] = _dweight(dkv2, h.view(B * S, D))
+            db = torch.empty(3 * D, dtype=torch.float32, device=h.device)
+            _colsum(dq2, db[:D])
+            _colsum(dkv2, db[D:])
+            return dw, db
+
+        dw, db = _SideWork.run((dq2, dkv2, h, h_cls), weight_grads)
         return dh, dw, db, None, None
 
 
@@ -330,6 +499,7 @@ class _AddLayerNorm(torch.autograd.Function):
             x_new = torch.empty(x.shape, dtype=torch.float32, device=x.device)
             seed = _seed_pair(x, p_drop)
         nv.add_ln_fwd(x.data_ptr(), row_stride, a, gamma, beta, x_new, h, stats[0], stats[1], T, eps, p_drop, *seed)
+        ctx.params = (gamma, beta)
         if a is None:
             ctx.save_for_backward(x, gamma, stats)
             ctx.meta = (row_stride, 0.0, (0, 0), False)
@@ -349,12 +519,17 @@ class _AddLayerNorm(torch.autograd.Function):
         T = xn.numel() // 256
         dx = torch.empty(xn.shape, dtype=torch.float32, device=xn.device)
         da = torch.empty(xn.shape, dtype=torch.bfloat16, device=xn.device) if has_a else None
-        dparams = torch.empty((3, 256), dtype=torch.float32, device=xn.device)
         if g_h is None:
             g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
         g_x = g_x.contiguous() if (has_a and g_x is not None) else None
-        nv.add_ln_bwd(xn.data_ptr(), row_stride, g_x, g_h.contiguous(), stats[0], stats[1], gamma, dx, da, dparams, T, p_drop,
-                      *seed)
+        sink = _sink_for(*ctx.params)
+        dparams = None if sink is not None else torch.empty((3, 256), dtype=torch.float32, device=xn.device)
+        ws = nv.add_ln_bwd(xn.data_ptr(), row_stride, g_x, g_h.contiguous(), stats[0], stats[1], gamma, dx, da, dparams, T, p_drop,
+                           *seed)
+        if sink is not None:
+            sink.add(ctx.params[0], ws, 768, 256, ws.shape[0])
+            sink.add(ctx.params[1], ws[:, 256:], 768, 256, ws.shape[0])
+            return dx, da, None, None, None, None
         return dx, da, dparams[0], dparams[1], None, None
 
 
@@ -378,6 +553,7 @@ class _LinearAddLayerNorm(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             a = F.linear(u, wb, bb)
         ctx.wbT, ctx.link = wbT, link
+        ctx.params = (weight, bias, gamma, beta)
         x, row_stride = _residual_rows(x)
         T = x.numel() // 256
         gamma, beta = gamma.contiguous(), beta.contiguous()
@@ -399,11 +575,17 @@ class _LinearAddLayerNorm(torch.autograd.Function):
         T = xn.numel() // 256
         dx = torch.empty(xn.shape, dtype=torch.float32, device=xn.device)
         da = torch.empty(xn.shape, dtype=torch.bfloat16, device=xn.device)
-        dparams = torch.empty((3, 256), dtype=torch.float32, device=xn.device)
+        weight, bias, gamma_p, beta_p = ctx.params
+        sink = _sink_for(weight, bias, gamma_p, beta_p)
+        dparams = None if sink is not None else torch.empty((3, 256), dtype=torch.float32, device=xn.device)
         if g_h is None:
             g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
-        nv.add_ln_bwd(xn.data_ptr(), 256, None if g_x is None else g_x.contiguous(), g_h.contiguous(), stats[0], stats[1],
-                      gamma, dx, da, dparams, T, p_drop, *seed)
+        ws = nv.add_ln_bwd(xn.data_ptr(), 256, None if g_x is None else g_x.contiguous(), g_h.contiguous(), stats[0], stats[1],
+                           gamma, dx, da, dparams, T, p_drop, *seed)
+        if sink is not None:
+            sink.add(gamma_p, ws, 768, 256, ws.shape[0])
+            sink.add(beta_p, ws[:, 256:], 768, 256, ws.shape[0])
+            sink.add(bias, ws[:, 512:], 768, 256, ws.shape[0])
         with torch.autocast("cuda", enabled=False):
             da2, u2 = da.view(T, 256), u.reshape(T, -1)
             du = None
@@ -411,13 +593,22 @@ class _LinearAddLayerNorm(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 if link is not None and ctx.wbT is not None and _stationary_ok(da2, ctx.wbT):
                     # u = dropout(relu(.)) of the same block: mask + 1/keep + linear1's bias gradient in the GEMM epilogue
-                    du, link.db = nv.linear_mask_bwd(da2, ctx.wbT, u2, link.p_drop)
+                    sink1 = _sink_for(link.bias_param)
+                    if sink1 is not None:
+                        du, ws1 = nv.linear_mask_bwd(da2, ctx.wbT, u2, link.p_drop, final=False)
+                        sink1.add(link.bias_param, ws1, ws1.shape[1], ws1.shape[1], ws1.shape[0])
+                        link.db, link.db_sunk = None, True
+                    else:
+                        du, link.db = nv.linear_mask_bwd(da2, ctx.wbT, u2, link.p_drop)
                     link.masked = True
                     du = du.view(u.shape)
                 else:
                     du = _hip_linear(da2, ctx.wbT) if ctx.wbT is not None else None
                     du = (da2 @ wb if du is None else du).view(u.shape)
-            dw = _dweight(da2, u2)
+            if sink is not None:
+                _sink_weight(sink, weight, da2, u2)
+                return du, None, None, None, None, dx, None, None, None, None, None, None
+            dw = _SideWork.run((da2, u2), lambda: _dweight(da2, u2))
         return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None, None
 
 
@@ -443,6 +634,9 @@ class _LinearReluDropout(torch.autograd.Function):
                 nv.relu_dropout_fwd(z, y, p_drop, *_seed_pair(z, p_drop))
         ctx.save_for_backward(h, wb, y)
         ctx.p_drop, ctx.link = p_drop, link
+        ctx.params = (weight, bias)
+        if link is not None:
+            link.bias_param = bias
         return y
 
     @staticmethod
@@ -451,18 +645,29 @@ class _LinearReluDropout(torch.autograd.Function):
 
         h, wb, y = ctx.saved_tensors
         link = ctx.link
+        weight, bias = ctx.params
+        sink = _sink_for(weight, bias)
+        db_done = False
         if link is not None and link.masked:
-            dz, db = dy.contiguous(), link.db
-            link.db, link.masked = None, False
+            dz, db, db_done = dy.contiguous(), link.db, link.db_sunk
+            link.db, link.masked, link.db_sunk = None, False, False
         else:
             dz = torch.empty_like(y)
-            db = torch.empty(y.shape[-1], dtype=torch.float32, device=y.device)
-            nv.relu_dropout_bwd(dy.contiguous(), y, dz, db, ctx.p_drop)
+            db = None if sink is not None else torch.empty(y.shape[-1], dtype=torch.float32, device=y.device)
+            ws = nv.relu_dropout_bwd(dy.contiguous(), y, dz, db, ctx.p_drop)
+            if sink is not None:
+                sink.add(bias, ws, ws.shape[1], ws.shape[1], ws.shape[0])
+                db_done = True
         with torch.autocast("cuda", enabled=False):
             dz2, h2 = dz.view(-1, dz.shape[-1]), h.reshape(-1, h.shape[-1])
             dh = (dz2 @ wb).view(h.shape) if ctx.needs_input_grad[0] else None
-            dw = _dweight(dz2, h2)
-        return dh, dw, db, None, None, None, None
+            if sink is not None:
+                _sink_weight(sink, weight, dz2, h2)
+                if not db_done:  # the link delivered a finished bias gradient: let the sink copy it into place
+                    sink.add(bias, db.contiguous(), db.numel(), db.numel(), 1)
+                return dh, None, None, None, None, None, None
+            dw = _SideWork.run((dz2, h2), lambda: _dweight(dz2, h2))
+        return dh, dw, (None if db_done else db), None, None, None, None
 
 
 def _fused_norm_ok(x: torch.Tensor, a) -> bool:

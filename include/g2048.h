@@ -216,7 +216,8 @@ int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void *a, const 
  * on x_new from the residual stream; g_h bf16 [T][256].  dx f32 [T][256] = g_x + dLayerNorm (gradient for x);
  * da bf16 [T][256] or NULL = dropout-masked dx (gradient for a); dparams f32 [3][256] = dgamma, dbeta and the column
  * sums of da (= the bias gradient of the Linear that produced a; zeros when da is NULL), summed in a fixed order;
- * workspace: g2048_add_ln_bwd_workspace_floats(T) floats of scratch. */
+ * workspace: g2048_add_ln_bwd_workspace_floats(T) floats of scratch.  dparams NULL: first stage only, the workspace then
+ * holds f32 [workspace floats / 768][3 * 256] partial sums (dgamma | dbeta | bias gradient) for g2048_reduce_jobs. */
 int64_t g2048_add_ln_bwd_workspace_floats(int64_t T);
 int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
                      const float *rstd, const float *gamma, float *dx, void *da, float *dparams, float *workspace,
@@ -229,9 +230,11 @@ int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x
  * than 1024 columns are summed in column tiles of 1024), row_stride >= N.
  * The bias gradient of every Linear in the update, and the CLS-token gradient (reference: nn.Linear inside
  * src/ppo/transformer_encoder.py:138-148 and src/ppo/ppo_agent.py:59-86; PyTorch computes it with at::sum).
- * workspace: g2048_colsum_workspace_floats(T, N) floats of scratch. */
+ * workspace: g2048_colsum_workspace_floats(T, N) floats of scratch.  out NULL (N <= 1024 only): first stage only, the
+ * workspace then holds f32 [g2048_colsum_partial_rows(T, N)][N] partial sums for g2048_reduce_jobs. */
 #define G2048_COLSUM_MAX_GROUPS 512
 int64_t g2048_colsum_workspace_floats(int64_t T, int N);
+int64_t g2048_colsum_partial_rows(int64_t T, int N);
 int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int64_t T, int N, float *workspace, float *out,
                  void *stream);
 
@@ -259,7 +262,8 @@ int g2048_relu_dropout_fwd(const void *x, void *y, int64_t T, int F, float p_dro
                            const uint64_t *seed_state, void *stream);
 /* dx = dy / (1 - p_drop) where y != 0, else 0 (y is non-zero exactly where the unit was active and kept: neither x nor
  * a mask is needed); dbias f32 [F] = column sums of dx in a fixed order = the bias gradient of the Linear in front.
- * dx may alias dy.  workspace: g2048_relu_dropout_bwd_workspace_floats(T, F) floats. */
+ * dx may alias dy.  workspace: g2048_relu_dropout_bwd_workspace_floats(T, F) floats.  dbias NULL: first stage only, the
+ * workspace then holds f32 [workspace floats / F][F] partial sums for g2048_reduce_jobs. */
 int64_t g2048_relu_dropout_bwd_workspace_floats(int64_t T, int F);
 int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, float *workspace, int64_t T, int F,
                            float p_drop, void *stream);
@@ -286,6 +290,7 @@ int g2048_linear_relu_dropout_bf16(const void *x, int64_t ldx, const void *weigh
  * dz in a fixed order = linear1's bias gradient.  Replaces g2048_linear_bf16 + g2048_relu_dropout_bwd.  K <= 256;
  * y_saved bf16 [T][ldm]; workspace: g2048_linear_mask_bwd_workspace_floats(T, N) floats. */
 int64_t g2048_linear_mask_bwd_workspace_floats(int64_t T, int N);
+int64_t g2048_linear_mask_bwd_partial_rows(int64_t T, int N); /* dbias NULL: workspace = f32 [rows][N] partial sums */
 int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const void *weight_t, int64_t ldw, const void *y_saved, int64_t ldm,
                                void *dz, int64_t lddz, float *dbias, float *workspace, int64_t T, int K, int N, float p_drop,
                                void *stream);
@@ -307,9 +312,25 @@ int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, fl
 
 /* ---- PPO update: minibatch assembly ------------------------------------------------------------------------ */
 
+/* ---- gradient reductions of the update, second stage ----------------------------------------------------------- */
+
+/* All second-stage reductions of one backward pass in one launch (per 64 jobs): for every job,
+ * dst[c] = sum over p < parts of src[p * part_stride + c], c < n, in f32 and in a fixed order.  Jobs: the 16 split-K
+ * slices of a weight gradient (bf16 [16][out * in]), the per-workgroup partial column sums the backward kernels leave in
+ * their workspace when called with a NULL result pointer (g2048_add_ln_bwd, g2048_relu_dropout_bwd,
+ * g2048_linear_mask_bwd_bf16, g2048_embed_bwd, g2048_colsum: f32 [rows][N], rows = workspace floats / N), a bf16 -> f32
+ * conversion (parts 1).  Replaces what PyTorch runs as one at::sum / copy kernel per parameter
+ * (reference: loss.backward() at src/ppo/ppo_trainer.py:410-414).  jobs: host array, read during the call; src 2- (bf16) or
+ * 4-byte aligned device memory, vector loads when 8-/16-byte aligned with part_stride % 4 == 0. */
+#define G2048_REDUCE_MAX_JOBS 64
+typedef struct {
+    const void *src; float *dst; int64_t part_stride; int32_t n, parts, src_bf16, reserved;
+} g2048_reduce_job;
+int g2048_reduce_jobs(const g2048_reduce_job *jobs, int n_jobs, void *stream);
+
 /* ---- optimiser step (update) ---------------------------------------------------------------------------- */
 
-/* One optimiser step for every parameter of the agent in two launches: GradScaler unscale + inf check, gradient-norm
+/* One optimiser step for every parameter of the agent in three launches: GradScaler unscale + inf check, gradient-norm
  * clipping, AdamW, GradScaler update (reference: src/ppo/ppo_trainer.py:413-434 = scaler.unscale_(opt);
  * clip_grad_norm_(params, max_grad_norm); scaler.step(opt); scaler.update(), with opt = torch.optim.AdamW built by
  * src/optim/configure_optimizers.py:16-127).
@@ -322,8 +343,7 @@ int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, fl
  * scale / growth_tracker: the GradScaler's device scalars, or NULL/NULL when no scaler is used (then gradients are taken
  * as they are and nothing is skipped); with a scaler, a step whose gradients hold an inf/nan changes neither parameters
  * nor moments nor steps, and the scale is multiplied by backoff; after growth_interval consecutive clean steps by growth.
- * workspace: g2048_opt_workspace_floats(n_chunks) floats whose LAST 4 words the caller zeroed once (a completion
- * counter the kernel leaves at zero).  info (optional, device f32[2]): total gradient norm before clipping, found_inf.
+ * workspace: g2048_opt_workspace_floats(n_chunks) floats.  info (optional, device f32[2]): total gradient norm before clipping, found_inf.
  * Arithmetic is torch's fused AdamW (bias corrections in f64 from the step count); the summation order of the norm is
  * fixed by the chunk table. */
 #define G2048_OPT_CHUNK 2048

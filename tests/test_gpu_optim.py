@@ -1,4 +1,4 @@
-"""g2048_opt_step (clip + AdamW + GradScaler in two launches) against the PyTorch calls of the reference's update loop
+"""g2048_opt_step (clip + AdamW + GradScaler in three launches) against the PyTorch calls of the reference's update loop
 (src/ppo/ppo_trainer.py:413-434): scaler.unscale_, clip_grad_norm_, scaler.step(AdamW), scaler.update."""
 import copy
 
@@ -127,7 +127,7 @@ def _trainer(dev, agent, log_dir, **kw):
 
 
 def test_trainer_update_with_flat_step_matches_torch_step(dev, tmp_path, monkeypatch):
-    """The same rollouts and minibatches through update_policy with the kernel pair and with PyTorch's calls
+    """The same rollouts and minibatches through update_policy with g2048_opt_step and with PyTorch's calls
     (G2048_FLAT_OPT=0): parameters agree to f32 rounding after several optimiser steps (dropout off, eager mode)."""
     monkeypatch.chdir(tmp_path)
 
@@ -165,3 +165,72 @@ def test_trainer_update_with_flat_step_matches_torch_step(dev, tmp_path, monkeyp
     assert float(tr_f._flat_step.steps[0]) == m_f["n_updates"]
     m2 = tr_f.update_policy(batch_size=256, n_epochs=1)  # and keeps training
     assert m2["n_updates"] >= 2 and np.isfinite(m2["total_loss"])
+
+
+def test_reduce_jobs_kernel(dev):
+    """g2048_reduce_jobs: many jobs of mixed dtype / parts / widths in one call, vs f64 sums; ragged widths, strided
+    sources (column blocks of a wider partial matrix), > 64 jobs (two launches), bit-reproducible."""
+    from src.g2048 import native as nv
+
+    torch.manual_seed(31)
+    jobs, want, outs = [], [], []
+    shapes = [(16, 768 * 256, torch.bfloat16), (16, 256 * 256, torch.bfloat16), (1, 4 * 512, torch.bfloat16), (1, 513, torch.bfloat16),
+              (544, 256, torch.float32), (64, 1024, torch.float32), (3, 1, torch.float32), (7, 6, torch.bfloat16), (1, 1, torch.float32)]
+    for rep in range(8):  # 72 + 24 jobs
+        for parts, n, dt in shapes:
+            src = torch.randn(parts, n, device=dev).to(dt)
+            dst = torch.full((n,), float("nan"), device=dev)
+            jobs.append((src, dst, n, n, parts))
+            want.append(src.double().sum(0))
+            outs.append(dst)
+        wide = torch.randn(100, 768, device=dev)  # three column blocks of one partial matrix (the add+LN backward's layout)
+        for c in range(3):
+            dst = torch.empty(256, device=dev)
+            jobs.append((wide[:, 256 * c:], dst, 768, 256, 100))
+            want.append(wide[:, 256 * c:256 * (c + 1)].double().sum(0))
+            outs.append(dst)
+    nv.reduce_jobs(jobs)
+    for (src, dst, stride, n, parts), w, o in zip(jobs, want, outs):
+        tol = 1e-6 * float(src.float().abs().sum(0).max()) + 1e-7
+        assert torch.allclose(o.double(), w, rtol=1e-6, atol=tol), (parts, n, src.dtype, (o.double() - w).abs().max().item())
+    first = [o.clone() for o in outs]
+    nv.reduce_jobs(jobs)
+    assert all(torch.equal(a, b) for a, b in zip(first, outs))
+    nv.reduce_jobs([])
+
+
+def test_grad_sink_equals_per_parameter_reductions(dev, tmp_path, monkeypatch):
+    """One backward at the default model shape with the GradSink (one reduction launch) and without (at::sum /
+    k_colsum_final per parameter): every gradient agrees to f32 summation-order accuracy, and every parameter gets one."""
+    monkeypatch.chdir(tmp_path)
+
+    def grads(sink_on):
+        monkeypatch.setenv("G2048_GRAD_SINK", "1" if sink_on else "0")
+        torch.manual_seed(7)
+        agent = PPOAgent(hidden_dim=512, d_model=256, nhead=8, num_layers=2, dim_feedforward=1024, dropout=0.0, reduction="cls")
+        tr = _trainer(dev, agent, tmp_path / ("s" if sink_on else "n"), use_hip_graph=False, rollout_amp=True)
+        assert tr.grad_sink == sink_on and tr._flat_grad is not None
+        tr.collect_rollouts(batch_size=64, num_batches=1)
+        data = tr.rollout_buffer.device_data(dev)
+        M = 2048
+        assert data["boards"].shape[0] >= M
+        sample = dict(obs=data["boards"][:M].contiguous(), actions=data["actions"][:M].contiguous(),
+                      masks=data["masks"][:M].contiguous(), old_lp=data["log_probs"][:M].contiguous(),
+                      adv=data["raw_advantages"][:M].clamp(-3, 3).contiguous(), ret=data["raw_returns"][:M].clamp(-3, 3).contiguous())
+        agent.train()
+        tr._loss_backward(**sample)
+        assert all(p.grad is not None for p in agent.parameters())
+        tr._allreduce_grads()  # gathers the gradients autograd produced into the bucket (world 1: no collective)
+        return {n: p.grad.detach().clone() for n, p in agent.named_parameters()}, tr
+
+    g_s, tr_s = grads(True)
+    g_n, _ = grads(False)
+    assert set(g_s) == set(g_n)
+    for n in g_s:
+        a, b = g_s[n], g_n[n]
+        assert torch.isfinite(a).all(), n
+        err = (a - b).norm() / b.norm().clamp_min(1e-20)
+        assert err < 2e-3, (n, err.item())  # split-K slices are bf16 either way; only the order of the f32 sums differs
+    # and the bucket holds exactly these values (what the optimiser kernel reads)
+    for p, v in zip(tr_s._params, tr_s._flat_views):
+        assert p.grad.data_ptr() == v.data_ptr()
