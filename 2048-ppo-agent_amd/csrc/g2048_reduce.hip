@@ -14,7 +14,13 @@
 
 namespace {
 
+// Two workgroup shapes, chosen per job on the host:
+//   few parts (the split-K slices of a weight gradient, n up to 786 432): 256 threads x 4 columns, every thread walks the
+//     parts of its columns itself, four loads in flight - coalesced 512-byte rows per wave, no LDS;
+//   many parts (per-workgroup partial column sums, n <= 1024): 16 column groups x 16 part-slices, combined through LDS.
 constexpr int RJ_TX = 16, RJ_TY = 16, RJ_VEC = 4, RJ_COLS = RJ_TX * RJ_VEC;  // 64 columns x 16 part-slices per workgroup
+constexpr int RJ_THREADS = RJ_TX * RJ_TY, RJ_WIDE_COLS = RJ_THREADS * RJ_VEC;   // 1024 columns per workgroup
+constexpr int RJ_WIDE_MAX_PARTS = 32;
 constexpr int RJ_MAX = G2048_REDUCE_MAX_JOBS;
 
 struct JobTable {
@@ -28,11 +34,14 @@ __device__ __forceinline__ float bf2f(uint32_t hi16) { return __uint_as_float(hi
 __global__ void __launch_bounds__(RJ_TX * RJ_TY)
 k_reduce_jobs(JobTable T) {
     __shared__ float red[RJ_TY][RJ_COLS + 4];
+    static_assert(RJ_THREADS == 256, "");
     int j = 0;
     while (j + 1 < T.n_jobs && (int)blockIdx.x >= T.first_block[j + 1]) ++j;  // <= 64 entries, uniform
     const g2048_reduce_job J = T.job[j];
-    const int tx = threadIdx.x % RJ_TX, ty = threadIdx.x / RJ_TX;
-    const int c0 = ((int)blockIdx.x - T.first_block[j]) * RJ_COLS + tx * RJ_VEC;
+    const bool wide = J.parts <= RJ_WIDE_MAX_PARTS;
+    const int tx = wide ? (int)threadIdx.x : (int)threadIdx.x % RJ_TX, ty = wide ? 0 : (int)threadIdx.x / RJ_TX;
+    const int p_step = wide ? 1 : RJ_TY;
+    const int c0 = ((int)blockIdx.x - T.first_block[j]) * (wide ? RJ_WIDE_COLS : RJ_COLS) + tx * RJ_VEC;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c0 < J.n) {
         const bool vec = c0 + RJ_VEC <= J.n && !(J.part_stride & 3) && !((uintptr_t)J.src & (J.src_bf16 ? 7 : 15));
@@ -64,15 +73,24 @@ k_reduce_jobs(JobTable T) {
             return v;
         };
         int p = ty;
-        for (; p + 3 * RJ_TY < J.parts; p += 4 * RJ_TY) {  // four independent loads in flight, added in a fixed order
-            const float4 u0 = load(p), u1 = load(p + RJ_TY), u2 = load(p + 2 * RJ_TY), u3 = load(p + 3 * RJ_TY);
+        for (; p + 3 * p_step < J.parts; p += 4 * p_step) {  // four independent loads in flight, added in a fixed order
+            const float4 u0 = load(p), u1 = load(p + p_step), u2 = load(p + 2 * p_step), u3 = load(p + 3 * p_step);
             a0 += (u0.x + u1.x) + (u2.x + u3.x); a1 += (u0.y + u1.y) + (u2.y + u3.y);
             a2 += (u0.z + u1.z) + (u2.z + u3.z); a3 += (u0.w + u1.w) + (u2.w + u3.w);
         }
-        for (; p < J.parts; p += RJ_TY) {
+        for (; p < J.parts; p += p_step) {
             const float4 u = load(p);
             a0 += u.x; a1 += u.y; a2 += u.z; a3 += u.w;
         }
+    }
+    if (wide) {  // (uniform per workgroup)
+        if (c0 + RJ_VEC <= J.n && !((uintptr_t)J.dst & 15)) {
+            *reinterpret_cast<float4 *>(J.dst + c0) = make_float4(a0, a1, a2, a3);
+        } else if (c0 < J.n) {
+            const float s[4] = {a0, a1, a2, a3};
+            for (int q = 0; q < 4 && c0 + q < J.n; ++q) J.dst[c0 + q] = s[q];
+        }
+        return;
     }
     float *r = &red[ty][tx * RJ_VEC];
     r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3;
@@ -101,7 +119,8 @@ extern "C" int g2048_reduce_jobs(const g2048_reduce_job *jobs, int n_jobs, void 
         for (int i = 0; i < T.n_jobs; ++i) {
             T.job[i] = jobs[base + i];
             T.first_block[i] = blocks;
-            blocks += (jobs[base + i].n + RJ_COLS - 1) / RJ_COLS;
+            const int cols = jobs[base + i].parts <= RJ_WIDE_MAX_PARTS ? RJ_WIDE_COLS : RJ_COLS;
+            blocks += (jobs[base + i].n + cols - 1) / cols;
         }
         for (int i = T.n_jobs; i <= RJ_MAX; ++i) T.first_block[i] = blocks;
         hipLaunchKernelGGL(k_reduce_jobs, dim3((unsigned)blocks), dim3(RJ_TX * RJ_TY), 0, (hipStream_t)stream, T);

@@ -30,7 +30,7 @@ def bench(fn, n=30):
 
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 34816
-for K, N in ((256, 256), (256, 768), (256, 1024), (1024, 256), (768, 256), (256, 512), (512, 256)):
+for K, N in ((256, 256), (256, 768), (256, 1024), (1024, 256), (768, 256), (256, 512), (512, 256), (512, 512)):
     x = torch.randn(T, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
     b = torch.randn(N, device=dev)
