@@ -15,9 +15,12 @@
 // The same kernel computes dX = dY . W with the transposed weight W^T[K][N] as its "weight".
 // Two fused epilogues for the feed-forward block of the encoder layer (K <= 256 kernel only):
 //   EPI_RELU_DROPOUT  y = dropout(relu(x W1^T + b1)) - linear1 forward without the bf16 round trip of the pre-activation;
-//   EPI_MASK_COLSUM   dz = (dy W2) / keep where the saved activation is non-zero, else 0, plus the column sums of dz
-//                     (= linear1's bias gradient): the input gradient of linear2 fused with the backward of
-//                     relu + dropout (replaces g2048_relu_dropout_bwd's pass over two [T][1024] matrices).
+//                     It can also leave one bit per output (non-zero or not) in a side buffer, in the layout of the
+//                     kernel's accumulators: 64 bits per lane and tile.
+//   EPI_MASK_COLSUM   dz = (dy W2) / keep where that bit is set, else 0, plus the column sums of dz (= linear1's bias
+//                     gradient): the input gradient of linear2 fused with the backward of relu + dropout (replaces
+//                     g2048_relu_dropout_bwd's pass over two [T][1024] matrices; the mask costs 1/16 of re-reading
+//                     the activation).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,10 +35,10 @@ struct Epi {
     uint32_t thr16, s0, s1;         // EPI_RELU_DROPOUT: keep threshold on 16 hash bits, seed words
     const uint64_t *seed_state;     // optional device-resident word mixed into the seed (hipGraph replays)
     int64_t row_elems;              // elements per output row in the dropout index (= N)
-    const uint16_t *mask;           // EPI_MASK_COLSUM: saved activation bf16 [T][ldm]
-    int64_t ldm;
+    uint2 *bits;                    // EPI_RELU_DROPOUT (optional, written) / EPI_MASK_COLSUM (read): [tiles][N/128][256] x 64 bits
     float *partial;                 // [gridDim.x][N] column sums of this workgroup's tiles
     int N;
+    uint32_t hi_term;               // EPI_RELU_DROPOUT: contribution of the seed's high word, constant per launch
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -70,12 +73,11 @@ __device__ __forceinline__ void dma_chunk(char *dst, const __bf16 *w_slice, int6
 // 8 consecutive outputs = one 16-byte store each.  Executed by all 64 lanes (the swap needs EXEC all ones).
 template <bool HAS_BIAS, int EPI>
 __device__ __forceinline__ void store_tile(f32x16 acc[4], const float *__restrict__ bias, __bf16 *yrow, int n0, int h, bool valid,
-                                           const Epi &E, int64_t tok, float *colacc) {
-    uint4 mk[8];
-    if (EPI == EPI_MASK_COLSUM) {  // the saved activations of this lane's 64 outputs, in the layout of the stores below
-        const uint16_t *mrow = E.mask + tok * E.ldm + n0 + 8 * h;
-        for (int q = 0; q < 8; ++q) mk[q] = *reinterpret_cast<const uint4 *>(mrow + 32 * (q >> 1) + 16 * (q & 1));
-    }
+                                           const Epi &E, int64_t tok, uint2 *bits_slot, uint2 bits_in, float *colacc) {
+    uint32_t obits[2] = {0u, 0u};  // bit 16 j + i of the pair: output (j, i) of this lane is non-zero
+    // element index of output (j = 0, i = 0) halved: one hash covers two neighbouring columns.  32 bits are enough for the
+    // index (a wrap only repeats masks after 2^33 outputs); the seed's high word enters through E.hi_term
+    const uint32_t pair0 = (uint32_t)(((uint64_t)tok * (uint64_t)E.row_elems + (uint64_t)(n0 + 4 * h)) >> 1);
     for (int j = 0; j < 4; ++j) {
         if (HAS_BIAS)
             for (int g = 0; g < 4; ++g) {
@@ -86,9 +88,7 @@ __device__ __forceinline__ void store_tile(f32x16 acc[4], const float *__restric
             for (int i = 0; i < 16; i += 2) {
                 float a = fmaxf(acc[j][i], 0.f), b = fmaxf(acc[j][i + 1], 0.f);
                 if (E.thr16) {  // one 32-bit hash per pair of neighbouring columns, 16 bits each
-                    const uint64_t pair = (uint64_t)(tok * E.row_elems + n0 + 32 * j + (i & 3) + 8 * (i >> 2) + 4 * h) >> 1;
-                    uint32_t x = (uint32_t)pair * 0x9E3779B1u ^ E.s0;
-                    x ^= (uint32_t)(pair >> 32) * 0x85EBCA77u + E.s1;
+                    uint32_t x = (pair0 + (uint32_t)(16 * j + ((i & 3) >> 1) + 4 * (i >> 2))) * 0x9E3779B1u + E.hi_term;
                     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
                     a = (x & 0xFFFFu) >= E.thr16 ? a * E.inv_keep : 0.f;
                     b = (x >> 16) >= E.thr16 ? b * E.inv_keep : 0.f;
@@ -96,20 +96,26 @@ __device__ __forceinline__ void store_tile(f32x16 acc[4], const float *__restric
                 acc[j][i] = a; acc[j][i + 1] = b;
             }
         }
-        if (EPI == EPI_MASK_COLSUM)
-            for (int i = 0; i < 16; ++i) acc[j][i] *= E.inv_keep;
+        if (EPI == EPI_MASK_COLSUM) {
+            const uint32_t w = j < 2 ? bits_in.x : bits_in.y;
+            for (int i = 0; i < 16; ++i) acc[j][i] = ((w >> (16 * (j & 1) + i)) & 1u) ? acc[j][i] * E.inv_keep : 0.f;
+        }
         for (int m = 0; m < 2; ++m) {
             uint32_t ax = pack2(acc[j][8 * m + 0], acc[j][8 * m + 1]), ay = pack2(acc[j][8 * m + 2], acc[j][8 * m + 3]);
             uint32_t bx = pack2(acc[j][8 * m + 4], acc[j][8 * m + 5]), by = pack2(acc[j][8 * m + 6], acc[j][8 * m + 7]);
+            if (EPI == EPI_RELU_DROPOUT) {  // non-zero AFTER rounding to bf16: exactly what the weight-gradient GEMM will read
+                const uint32_t pk[4] = {ax, ay, bx, by};
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t nz = ((pk[q] & 0x7FFFu) ? 1u : 0u) | ((pk[q] & 0x7FFF0000u) ? 2u : 0u);
+                    obits[j >> 1] |= nz << (16 * (j & 1) + 8 * m + 2 * q);
+                }
+            }
             const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
             const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
             uint32_t o[4] = {sx[0], sy[0], sx[1], sy[1]};
             if (EPI == EPI_MASK_COLSUM) {
-                const uint4 mm = mk[2 * j + m];
-                const uint32_t mw[4] = {mm.x, mm.y, mm.z, mm.w};
                 for (int q = 0; q < 4; ++q) {
-                    const uint32_t keep = ((mw[q] & 0x7FFFu) ? 0xFFFFu : 0u) | ((mw[q] & 0x7FFF0000u) ? 0xFFFF0000u : 0u);
-                    o[q] = valid ? (o[q] & keep) : 0u;
+                    if (!valid) o[q] = 0u;
                     colacc[8 * (2 * j + m) + 2 * q] += __uint_as_float(o[q] << 16);
                     colacc[8 * (2 * j + m) + 2 * q + 1] += __uint_as_float(o[q] & 0xFFFF0000u);
                 }
@@ -117,6 +123,7 @@ __device__ __forceinline__ void store_tile(f32x16 acc[4], const float *__restric
             if (valid) *reinterpret_cast<uint4 *>(yrow + 32 * j + 16 * m) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
+    if (EPI == EPI_RELU_DROPOUT && bits_slot) *bits_slot = make_uint2(obits[0], obits[1]);
 }
 
 // K > 256: the weight slice streams through two LDS buffers once per 128-token tile.
@@ -170,7 +177,7 @@ k_linear(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ w
         __syncthreads();  // every wave is done with this buffer
         if (c + NBUF < n_chunks) dma_chunk(smem + (c % NBUF) * CHUNK_BYTES, w_slice, ldw, c + NBUF, w, lane);
     }
-    store_tile<HAS_BIAS, EPI_NONE>(acc, bias, y + (tok0 + r) * ldy + n0 + 8 * h, n0, h, valid, Epi{}, 0, nullptr);
+    store_tile<HAS_BIAS, EPI_NONE>(acc, bias, y + (tok0 + r) * ldy + n0 + 8 * h, n0, h, valid, Epi{}, 0, nullptr, make_uint2(0u, 0u), nullptr);
 }
 
 // K <= 256: the weight slice (<= 64 KiB) is loaded ONCE and stays in LDS; the workgroup then walks over token tiles
@@ -199,17 +206,24 @@ k_linear_stationary(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__r
     for (int ks = 0; ks < 8; ++ks) aoff[ks] = r * 256 + (((2 * ks + h) ^ (r & 15)) * 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (EPI == EPI_RELU_DROPOUT && E.seed_state) {
-        const uint64_t sd = *E.seed_state;  // same mixing as the other dropout kernels (g2048_layernorm.hip)
-        E.s0 ^= (uint32_t)sd * 0x9E3779B1u;
-        E.s1 += (uint32_t)(sd >> 32) * 0x85EBCA77u + (uint32_t)sd;
+    if (EPI == EPI_RELU_DROPOUT) {
+        if (E.seed_state) {
+            const uint64_t sd = *E.seed_state;  // same mixing as the other dropout kernels (g2048_layernorm.hip)
+            E.s0 ^= (uint32_t)sd * 0x9E3779B1u;
+            E.s1 += (uint32_t)(sd >> 32) * 0x85EBCA77u + (uint32_t)sd;
+        }
+        E.hi_term = E.s0 ^ (E.s1 * 0x85EBCA77u);
     }
+    const int slices = gridDim.y;
     float colacc[EPI == EPI_MASK_COLSUM ? 64 : 1];
     for (int q = 0; q < (EPI == EPI_MASK_COLSUM ? 64 : 1); ++q) colacc[q] = 0.f;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t next = tile + gridDim.x;
         const uint4 *xnext = row_of(next < n_tiles ? next : tile);
+        uint2 *bits_slot = (EPI != EPI_NONE && E.bits) ? E.bits + ((tile * slices + blockIdx.y) * THREADS + tid) : nullptr;
+        uint2 bits_in = make_uint2(0u, 0u);
+        if (EPI == EPI_MASK_COLSUM) bits_in = *bits_slot;  // 8 bytes per lane, in flight behind the MFMAs
         f32x16 acc[4];
         for (int j = 0; j < 4; ++j)
             for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
@@ -227,7 +241,8 @@ k_linear_stationary(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__r
                 }
         }
         const int64_t tok = tile * TOK + 32 * w + r;
-        store_tile<HAS_BIAS, EPI>(acc, bias, y + tok * ldy + n0 + 8 * h, n0, h, tok < T, E, tok < T ? tok : T - 1, colacc);
+        store_tile<HAS_BIAS, EPI>(acc, bias, y + tok * ldy + n0 + 8 * h, n0, h, tok < T, E, tok < T ? tok : T - 1, bits_slot, bits_in,
+                                  colacc);
         xrow = xnext;
     }
     if (EPI == EPI_MASK_COLSUM) {
@@ -303,9 +318,13 @@ extern "C" int g2048_linear_bf16(const void *x, int64_t ldx, const void *weight,
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }
 
+extern "C" int64_t g2048_ffn_mask_bytes(int64_t T, int N) {
+    return (T <= 0 || N < NS || N % NS) ? 0 : ((T + TOK - 1) / TOK) * (N / NS) * THREADS * (int64_t)sizeof(uint2);
+}
+
 extern "C" int g2048_linear_relu_dropout_bf16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const float *bias, void *y,
                                               int64_t ldy, int64_t T, int K, int N, float p_drop, uint64_t seed,
-                                              const uint64_t *seed_state, void *stream) {
+                                              const uint64_t *seed_state, void *mask_bits, void *stream) {
     if (!operands_ok(x, ldx, weight, ldw, y, ldy, T, K, N, bias) || !bias || K > NBUF * KC || !(p_drop >= 0.f && p_drop < 1.f))
         return G2048_EINVAL;
     Epi E{};
@@ -314,6 +333,8 @@ extern "C" int g2048_linear_relu_dropout_bf16(const void *x, int64_t ldx, const 
     E.s0 = (uint32_t)seed; E.s1 = (uint32_t)(seed >> 32);
     E.seed_state = p_drop > 0.f ? seed_state : nullptr;
     E.row_elems = N;
+    E.bits = (uint2 *)mask_bits;
+    if ((uintptr_t)mask_bits & 7) return G2048_EINVAL;
     return launch_stationary<true, EPI_RELU_DROPOUT>((const __bf16 *)x, ldx, (const __bf16 *)weight, ldw, bias, (__bf16 *)y, ldy, T, K, N,
                                                      E, nullptr, (hipStream_t)stream);
 }
@@ -330,16 +351,15 @@ extern "C" int64_t g2048_linear_mask_bwd_partial_rows(int64_t T, int N) {
     return groups > n_tiles ? n_tiles : groups;
 }
 
-extern "C" int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const void *weight_t, int64_t ldw, const void *y_saved,
-                                          int64_t ldm, void *dz, int64_t lddz, float *dbias, float *workspace, int64_t T, int K,
-                                          int N, float p_drop, void *stream) {
-    if (!operands_ok(dy, lddy, weight_t, ldw, dz, lddz, T, K, N, nullptr) || K > NBUF * KC || !y_saved || ldm < N || (ldm & 7) ||
-        !workspace || (((uintptr_t)y_saved | (uintptr_t)workspace) & 15) || !(p_drop >= 0.f && p_drop < 1.f))
+extern "C" int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const void *weight_t, int64_t ldw, const void *mask_bits,
+                                          void *dz, int64_t lddz, float *dbias, float *workspace, int64_t T, int K, int N,
+                                          float p_drop, void *stream) {
+    if (!operands_ok(dy, lddy, weight_t, ldw, dz, lddz, T, K, N, nullptr) || K > NBUF * KC || !mask_bits ||
+        ((uintptr_t)mask_bits & 7) || !workspace || ((uintptr_t)workspace & 15) || !(p_drop >= 0.f && p_drop < 1.f))
         return G2048_EINVAL;
     Epi E{};
     E.inv_keep = 1.0f / (1.0f - p_drop);
-    E.mask = (const uint16_t *)y_saved;
-    E.ldm = ldm;
+    E.bits = (uint2 *)const_cast<void *>(mask_bits);
     E.partial = workspace;
     E.N = N;
     int groups = 0;

@@ -55,9 +55,10 @@ SIGNATURES = {
     "g2048_ppo_loss": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp,
                        _vp, _vp],
     "g2048_linear_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
-    "g2048_linear_relu_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_ffn_mask_bytes": [_i64, _i32],
+    "g2048_linear_relu_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, C.c_uint64, _vp, _vp, _vp],
     "g2048_linear_mask_bwd_workspace_floats": [_i64, _i32],
-    "g2048_linear_mask_bwd_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp],
+    "g2048_linear_mask_bwd_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp],
     "g2048_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_embed_bwd_workspace_floats": [_i64],
     "g2048_embed_bwd": [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
@@ -98,7 +99,7 @@ def load() -> C.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
-            fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_workspace_bytes", "_partial_rows")) else C.c_int
+            fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_workspace_bytes", "_partial_rows", "_mask_bytes")) else C.c_int
         if lib.g2048_abi_version() != 2:
             raise NativeError("libg2048.so ABI version mismatch")
         _lib = lib
@@ -476,37 +477,39 @@ def linear_bf16(x2: torch.Tensor, weight: torch.Tensor, bias_f32=None, out=None)
 
 
 def linear_relu_dropout(x2: torch.Tensor, weight: torch.Tensor, bias_f32: torch.Tensor, p_drop: float, seed: int = 0,
-                        seed_state: int = 0) -> torch.Tensor:
-    """dropout(relu(x2 @ weight^T + bias)) -> bf16 [T, N] in one launch (K <= 256); see g2048_linear_relu_dropout_bf16."""
+                        seed_state: int = 0, want_mask: bool = False):
+    """dropout(relu(x2 @ weight^T + bias)) -> bf16 [T, N] in one launch (K <= 256); see g2048_linear_relu_dropout_bf16.
+    ``want_mask``: -> (y, mask) with the opaque bit mask ``linear_mask_bwd`` reads."""
     if not linear_ok(x2, weight) or x2.shape[1] > 256:
         raise NativeError(f"linear_relu_dropout: unsupported operands {tuple(x2.shape)} {x2.dtype} x {tuple(weight.shape)}")
     T, K = x2.shape
     N = weight.shape[0]
     out = torch.empty((T, N), dtype=torch.bfloat16, device=x2.device)
+    mask = torch.empty(load().g2048_ffn_mask_bytes(T, N), dtype=u8, device=x2.device) if want_mask else None
     _check(load().g2048_linear_relu_dropout_bf16(x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0),
                                                  _dev(bias_f32, f32, N, "bias"), out.data_ptr(), N, T, K, N, float(p_drop),
-                                                 int(seed) & (2 ** 64 - 1), seed_state or None, _stream()),
+                                                 int(seed) & (2 ** 64 - 1), seed_state or None,
+                                                 mask.data_ptr() if want_mask else None, _stream()),
            "g2048_linear_relu_dropout_bf16")
-    return out
+    return (out, mask) if want_mask else out
 
 
-def linear_mask_bwd(dy2: torch.Tensor, weight_t: torch.Tensor, y_saved2: torch.Tensor, p_drop: float, final: bool = True):
-    """-> (dz bf16 [T, N], dbias f32 [N]): dz = (dy2 @ weight_t^T) / (1 - p) where y_saved2 != 0; see
-    g2048_linear_mask_bwd_bf16.  ``final`` False: (dz, partial sums f32 [rows, N]) for ``reduce_jobs``."""
+def linear_mask_bwd(dy2: torch.Tensor, weight_t: torch.Tensor, mask: torch.Tensor, p_drop: float, final: bool = True):
+    """-> (dz bf16 [T, N], dbias f32 [N]): dz = (dy2 @ weight_t^T) / (1 - p) where the forward's output was non-zero
+    (``mask`` from ``linear_relu_dropout(..., want_mask=True)`` with the same T and N); see g2048_linear_mask_bwd_bf16.
+    ``final`` False: (dz, partial sums f32 [rows, N]) for ``reduce_jobs``."""
     if not linear_ok(dy2, weight_t) or dy2.shape[1] > 256:
         raise NativeError(f"linear_mask_bwd: unsupported operands {tuple(dy2.shape)} {dy2.dtype} x {tuple(weight_t.shape)}")
     T, K = dy2.shape
     N = weight_t.shape[0]
-    if tuple(y_saved2.shape) != (T, N) or y_saved2.dtype != torch.bfloat16 or y_saved2.stride(1) != 1 \
-            or y_saved2.stride(0) % 8 or y_saved2.data_ptr() % 16:
-        raise NativeError(f"linear_mask_bwd: y_saved {tuple(y_saved2.shape)} {y_saved2.dtype} does not match [{T}, {N}] bf16")
+    if mask.dtype != u8 or not mask.is_cuda or mask.numel() != load().g2048_ffn_mask_bytes(T, N) or mask.data_ptr() % 8:
+        raise NativeError(f"linear_mask_bwd: the mask does not belong to a [{T}, {N}] forward call")
     dz = torch.empty((T, N), dtype=torch.bfloat16, device=dy2.device)
     db = torch.empty(N, dtype=f32, device=dy2.device) if final else None
     ws = torch.empty(load().g2048_linear_mask_bwd_workspace_floats(T, N), dtype=f32, device=dy2.device)
     _check(load().g2048_linear_mask_bwd_bf16(dy2.data_ptr(), dy2.stride(0), weight_t.data_ptr(), weight_t.stride(0),
-                                             y_saved2.data_ptr(), y_saved2.stride(0), dz.data_ptr(), N,
-                                             db.data_ptr() if final else None, ws.data_ptr(), T, K, N, float(p_drop), _stream()),
-           "g2048_linear_mask_bwd_bf16")
+                                             mask.data_ptr(), dz.data_ptr(), N, db.data_ptr() if final else None, ws.data_ptr(),
+                                             T, K, N, float(p_drop), _stream()), "g2048_linear_mask_bwd_bf16")
     if final:
         return dz, db
     rows = load().g2048_linear_mask_bwd_partial_rows(T, N)

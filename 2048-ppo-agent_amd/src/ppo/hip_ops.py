@@ -239,10 +239,11 @@ class FFNLink:
     bias gradient (``g2048_linear_mask_bwd_bf16``) and leaves both here for the backward of the first, which then has
     nothing left to launch for the activation."""
 
-    __slots__ = ("p_drop", "db", "masked", "bias_param", "db_sunk")
+    __slots__ = ("p_drop", "db", "masked", "bias_param", "db_sunk", "bits")
 
     def __init__(self, p_drop: float):
         self.p_drop, self.db, self.masked = float(p_drop), None, False
+        self.bits = None  # the forward kernel's bit mask (output non-zero or not), read by the masked-gradient GEMM
         self.bias_param, self.db_sunk = None, False  # linear1's bias; True when a GradSink took its gradient
 
 
@@ -250,7 +251,9 @@ def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """The first stage of ``_dweight``: bf16 [parts, out, in] whose sum over parts is dW (parts = 16 split-K slices for a
     long token axis, else 1)."""
     T, S = x2.shape[0], _LinearSplitK.SLICES
-    if T % S == 0 and T // S >= 1024:
+    # also for the 2048-row GEMMs of the CLS-only layer and the heads: their [out, in] results are a handful of tiles with a
+    # 2048-long reduction each (17 us per GEMM in the pipeline); the sink adds the slices at no extra launch
+    if T % S == 0 and T // S >= 128:
         return torch.bmm(dy2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1))
     return (dy2.t() @ x2).unsqueeze(0)
 
@@ -591,16 +594,16 @@ class _LinearAddLayerNorm(torch.autograd.Function):
             du = None
             link = ctx.link
             if ctx.needs_input_grad[0]:
-                if link is not None and ctx.wbT is not None and _stationary_ok(da2, ctx.wbT):
+                if link is not None and link.bits is not None and ctx.wbT is not None and _stationary_ok(da2, ctx.wbT):
                     # u = dropout(relu(.)) of the same block: mask + 1/keep + linear1's bias gradient in the GEMM epilogue
                     sink1 = _sink_for(link.bias_param)
                     if sink1 is not None:
-                        du, ws1 = nv.linear_mask_bwd(da2, ctx.wbT, u2, link.p_drop, final=False)
+                        du, ws1 = nv.linear_mask_bwd(da2, ctx.wbT, link.bits, link.p_drop, final=False)
                         sink1.add(link.bias_param, ws1, ws1.shape[1], ws1.shape[1], ws1.shape[0])
                         link.db, link.db_sunk = None, True
                     else:
-                        du, link.db = nv.linear_mask_bwd(da2, ctx.wbT, u2, link.p_drop)
-                    link.masked = True
+                        du, link.db = nv.linear_mask_bwd(da2, ctx.wbT, link.bits, link.p_drop)
+                    link.masked, link.bits = True, None
                     du = du.view(u.shape)
                 else:
                     du = _hip_linear(da2, ctx.wbT) if ctx.wbT is not None else None
@@ -626,7 +629,10 @@ class _LinearReluDropout(torch.autograd.Function):
         h2 = h.reshape(-1, h.shape[-1])
         with torch.autocast("cuda", enabled=False):
             if _stationary_ok(h2, wb) and bias.dtype == torch.float32:
-                y = nv.linear_relu_dropout(h2, wb, bias.detach(), p_drop, *_seed_pair(h2, p_drop)).view(*h.shape[:-1], wb.shape[0])
+                y = nv.linear_relu_dropout(h2, wb, bias.detach(), p_drop, *_seed_pair(h2, p_drop), want_mask=link is not None)
+                if link is not None:
+                    y, link.bits = y
+                y = y.view(*h.shape[:-1], wb.shape[0])
             else:
                 z = _hip_linear(h2, wb, bias)
                 z = F.linear(h, wb, bb) if z is None else z.view(*h.shape[:-1], wb.shape[0])

@@ -280,19 +280,24 @@ int g2048_linear_bf16(const void *x, int64_t ldx, const void *weight, int64_t ld
 /* y = dropout(relu(x . weight^T + bias)) in one launch: linear1 + activation + dropout of the encoder layer's feed-forward
  * block (reference: nn.TransformerEncoderLayer._ff_block, built at src/ppo/transformer_encoder.py:138-148).  Operands as
  * for g2048_linear_bf16 with K <= 256 and bias required; the pre-activation is never rounded to bf16.  seed / seed_state
- * as for g2048_attn_fwd.  The output is non-zero exactly where the unit was active and kept. */
+ * as for g2048_attn_fwd.  The output is non-zero exactly where the unit was active and kept; mask_bits (optional,
+ * g2048_ffn_mask_bytes(T, N) bytes, 8-byte aligned) receives one bit per output saying so, in an opaque layout that only
+ * g2048_linear_mask_bwd_bf16 with the same T and N reads. */
+int64_t g2048_ffn_mask_bytes(int64_t T, int N);
 int g2048_linear_relu_dropout_bf16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const float *bias, void *y,
                                    int64_t ldy, int64_t T, int K, int N, float p_drop, uint64_t seed,
-                                   const uint64_t *seed_state, void *stream);
-/* The backward of `y_saved = dropout(relu(.)); out = y_saved . W2^T` with respect to the pre-activation, in one GEMM:
- * dz[T][N] = (dy[T][K] . weight_t[N][K]^T) / (1 - p_drop) where y_saved != 0, else 0 (weight_t = W2^T, i.e. linear2's
- * weight [K][N] transposed to [N][K]; dy = the gradient of linear2's output), and dbias f32 [N] = column sums of the bf16
- * dz in a fixed order = linear1's bias gradient.  Replaces g2048_linear_bf16 + g2048_relu_dropout_bwd.  K <= 256;
- * y_saved bf16 [T][ldm]; workspace: g2048_linear_mask_bwd_workspace_floats(T, N) floats. */
+                                   const uint64_t *seed_state, void *mask_bits, void *stream);
+/* The backward of `y = dropout(relu(.)); out = y . W2^T` with respect to the pre-activation, in one GEMM:
+ * dz[T][N] = (dy[T][K] . weight_t[N][K]^T) / (1 - p_drop) where y != 0 (mask_bits of the forward call), else 0
+ * (weight_t = W2^T, i.e. linear2's weight [K][N] transposed to [N][K]; dy = the gradient of linear2's output), and
+ * dbias f32 [N] = column sums of the bf16 dz in a fixed order = linear1's bias gradient.  Replaces g2048_linear_bf16 +
+ * g2048_relu_dropout_bwd (which re-reads the [T][N] activation; the bit mask is 1/16 of it).  K <= 256;
+ * workspace: g2048_linear_mask_bwd_workspace_floats(T, N) floats; dbias NULL: first stage only, the workspace then holds
+ * f32 [g2048_linear_mask_bwd_partial_rows(T, N)][N] partial sums for g2048_reduce_jobs. */
 int64_t g2048_linear_mask_bwd_workspace_floats(int64_t T, int N);
-int64_t g2048_linear_mask_bwd_partial_rows(int64_t T, int N); /* dbias NULL: workspace = f32 [rows][N] partial sums */
-int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const void *weight_t, int64_t ldw, const void *y_saved, int64_t ldm,
-                               void *dz, int64_t lddz, float *dbias, float *workspace, int64_t T, int K, int N, float p_drop,
+int64_t g2048_linear_mask_bwd_partial_rows(int64_t T, int N);
+int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const void *weight_t, int64_t ldw, const void *mask_bits, void *dz,
+                               int64_t lddz, float *dbias, float *workspace, int64_t T, int K, int N, float p_drop,
                                void *stream);
 
 /* ---- policy network (update): token embedding of packed boards ---------------------------------------------- */

@@ -592,13 +592,15 @@ def test_fused_ffn_kernels(dev):
             # backward: dz = (dy @ W2) / keep where y_saved != 0
             dy = torch.randn(T, K, device=dev).to(torch.bfloat16)
             w2t = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)  # = linear2.weight^T, [N, K]
-            for p, ys in ((0.0, y), (0.1, nv.linear_relu_dropout(x, w, b, 0.1, seed=9))):
-                dz, db = nv.linear_mask_bwd(dy, w2t, ys, p)
+            for p in (0.0, 0.1):
+                ys, bits = nv.linear_relu_dropout(x, w, b, p, seed=9, want_mask=True)
+                assert torch.equal(ys, nv.linear_relu_dropout(x, w, b, p, seed=9))  # the mask output changes nothing else
+                dz, db = nv.linear_mask_bwd(dy, w2t, bits, p)
                 want = torch.where(ys != 0, (dy.float() @ w2t.float().t()) / (1 - p), torch.zeros((), device=dev))
                 assert rel(dz, want) < 4e-3, (T, K, N, p, rel(dz, want))
                 assert not (dz[ys == 0] != 0).any()
                 assert torch.allclose(db, dz.float().sum(0), rtol=1e-4, atol=1e-4 * float(dz.float().abs().sum(0).max()) + 1e-6)
-                dz2, db2 = nv.linear_mask_bwd(dy, w2t, ys, p)
+                dz2, db2 = nv.linear_mask_bwd(dy, w2t, bits, p)
                 assert torch.equal(dz, dz2) and torch.equal(db, db2)
     with pytest.raises(nv.NativeError):
         nv.linear_relu_dropout(torch.zeros(8, 512, device=dev, dtype=torch.bfloat16),
