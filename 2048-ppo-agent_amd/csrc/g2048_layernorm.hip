@@ -77,7 +77,9 @@ k_add_ln_fwd(const float *__restrict__ x, int64_t x_rs, const uint16_t *__restri
 }
 
 // xn: the tensor that was normalised (x_new, or x itself when there was no branch), row stride xn_rs.
-// g_x: gradient flowing into x_new from the residual stream (f32 [T][256], may be null); g_h: bf16 [T][256].
+// g_x: gradient flowing into x_new from the residual stream (f32, may be null): row r of it belongs to token row r * g_x_period
+// (period 1: one row per token; period 17: only the CLS rows of [B][17][256] carry a gradient, g_x is [B][256]);
+// g_h: bf16 [T][256].
 // dx (f32 [T][256]) = g_x + dLN;  da (bf16 [T][256], may be null) = dropout-masked dx.
 // partial[blockIdx][3][256]: this workgroup's column sums of g_h * xhat (-> dgamma), g_h (-> dbeta) and the bf16 values
 // written to da (-> the bias gradient of the Linear that produced a); summed over workgroups by k_colsum_final.
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(64 * WAVES)
 k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restrict__ g_x, const uint16_t *__restrict__ g_h,
              const float *__restrict__ mean_in, const float *__restrict__ rstd_in, const float *__restrict__ gamma,
              float *__restrict__ dx, uint16_t *__restrict__ da, float *__restrict__ partial,
-             int64_t T, float inv_keep, uint32_t thr, uint32_t s0, uint32_t s1, const uint64_t *seed_state) {
+             int64_t T, float inv_keep, uint32_t thr, uint32_t s0, uint32_t s1, const uint64_t *seed_state, int g_x_period) {
     mix_seed_state(seed_state, s0, s1);
     __shared__ float red[WAVES][3][D];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -111,7 +113,10 @@ k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restric
         }
         const float c1 = wave_sum(s1sum) * (1.0f / D), c2 = wave_sum(s2sum) * (1.0f / D);
         float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g_x) gx = reinterpret_cast<const float4 *>(g_x + row * D)[lane];
+        if (g_x) {
+            if (g_x_period == 1) gx = reinterpret_cast<const float4 *>(g_x + row * D)[lane];
+            else if (row % g_x_period == 0) gx = reinterpret_cast<const float4 *>(g_x + (row / g_x_period) * D)[lane];
+        }
         float o[4] = {gx.x, gx.y, gx.z, gx.w};
         for (int q = 0; q < 4; ++q) o[q] += rstd * (dxh[q] - c1 - xh[q] * c2);
         reinterpret_cast<float4 *>(dx + row * D)[lane] = make_float4(o[0], o[1], o[2], o[3]);
@@ -256,7 +261,8 @@ extern "C" int64_t g2048_add_ln_bwd_workspace_floats(int64_t T) {
 
 extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
                                 const float *rstd, const float *gamma, float *dx, void *da, float *dparams, float *workspace,
-                                int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream) {
+                                int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, int g_x_period, void *stream) {
+    if (g_x_period < 1) return G2048_EINVAL;
     if (!x_norm || !g_h || !mean || !rstd || !gamma || !dx || !workspace || T <= 0 || (x_row_stride & 3) ||
         !(p_drop >= 0.f && p_drop < 1.f) || (((uintptr_t)x_norm | (uintptr_t)g_x | (uintptr_t)dx | (uintptr_t)gamma) & 15) ||
         (((uintptr_t)g_h | (uintptr_t)da) & 7))
@@ -265,7 +271,7 @@ extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const
     const int64_t blocks = (T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     hipLaunchKernelGGL(k_add_ln_bwd, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream, x_norm, x_row_stride, g_x,
                        (const uint16_t *)g_h, mean, rstd, gamma, dx, (uint16_t *)da, workspace, T, 1.0f / (1.0f - p_drop), thr,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
+                       (uint32_t)seed, (uint32_t)(seed >> 32), seed_state, g_x_period);
     if (dparams)
         hipLaunchKernelGGL(k_colsum_final, dim3(3 * D / CF_COLS), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream, workspace, (int)blocks,
                            3 * D, dparams);

@@ -108,6 +108,7 @@ k_reduce_jobs(JobTable T) {
 
 extern "C" int g2048_reduce_jobs(const g2048_reduce_job *jobs, int n_jobs, void *stream) {
     if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return G2048_EINVAL;
+    if (n_jobs == 0) return 0;
     for (int i = 0; i < n_jobs; ++i)
         if (!jobs[i].src || !jobs[i].dst || jobs[i].n <= 0 || jobs[i].parts <= 0 || (jobs[i].parts > 1 && jobs[i].part_stride < jobs[i].n) ||
             ((uintptr_t)jobs[i].src & (jobs[i].src_bf16 ? 1 : 3)) || ((uintptr_t)jobs[i].dst & 3))

@@ -70,7 +70,7 @@ SIGNATURES = {
     "g2048_reduce_jobs": [_vp, _i32, _vp],
     "g2048_add_ln_bwd_workspace_floats": [_i64],
     "g2048_add_ln_bwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp,
-                         _vp],
+                         _i32, _vp],
     "g2048_relu_dropout_fwd": [_vp, _vp, _i64, _i32, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_relu_dropout_bwd_workspace_floats": [_i64, _i32],
     "g2048_relu_dropout_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, C.c_float, _vp],
@@ -349,16 +349,16 @@ def add_ln_fwd(x_ptr: int, x_row_stride: int, a, gamma, beta, x_new, h, mean, rs
 
 
 def add_ln_bwd(xn_ptr: int, x_row_stride: int, g_x, g_h, mean, rstd, gamma, dx, da, dparams, T: int,
-               p_drop: float, seed: int, seed_state: int = 0):
+               p_drop: float, seed: int, seed_state: int = 0, g_x_period: int = 1):
     """dparams f32 [3, 256]: dgamma, dbeta, column sums of da.  dparams None: first stage only -> the workspace, f32
     [rows, 768] partial sums (for ``reduce_jobs``)."""
     bf = torch.bfloat16
     ws = torch.empty(load().g2048_add_ln_bwd_workspace_floats(T), dtype=f32, device=dx.device)
-    _check(load().g2048_add_ln_bwd(xn_ptr, int(x_row_stride), _dev(g_x, f32, 256 * T, "g_x", optional=True),
+    _check(load().g2048_add_ln_bwd(xn_ptr, int(x_row_stride), _dev(g_x, f32, 256 * (T // g_x_period), "g_x", optional=True),
                                    _dev(g_h, bf, 256 * T, "g_h"), _dev(mean, f32, T, "mean"), _dev(rstd, f32, T, "rstd"),
                                    _dev(gamma, f32, 256, "gamma"), _dev(dx, f32, 256 * T, "dx"),
                                    _dev(da, bf, 256 * T, "da", optional=True), _dev(dparams, f32, 768, "dparams", optional=True),
-                                   ws.data_ptr(), T, float(p_drop), int(seed), seed_state or None, _stream()),
+                                   ws.data_ptr(), T, float(p_drop), int(seed), seed_state or None, int(g_x_period), _stream()),
            "g2048_add_ln_bwd")
     return ws.view(-1, 768) if dparams is None else None
 

@@ -490,6 +490,7 @@ class _AddLayerNorm(torch.autograd.Function):
     def forward(ctx, x, a, gamma, beta, eps, p_drop):
         from ..g2048 import native as nv
 
+        ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None, not as a zero-filled tensor
         x, row_stride = _residual_rows(x)
         T = x.numel() // 256
         gamma, beta = gamma.contiguous(), beta.contiguous()
@@ -504,11 +505,11 @@ class _AddLayerNorm(torch.autograd.Function):
         nv.add_ln_fwd(x.data_ptr(), row_stride, a, gamma, beta, x_new, h, stats[0], stats[1], T, eps, p_drop, *seed)
         ctx.params = (gamma, beta)
         if a is None:
+            # x itself is the first output: the residual stream continues from THIS node, so the gradient of the stream and
+            # the LayerNorm gradient meet in one backward kernel instead of an accumulate kernel over [B, 17, 256]
             ctx.save_for_backward(x, gamma, stats)
             ctx.meta = (row_stride, 0.0, (0, 0), False)
-            unused = x.new_empty(0)
-            ctx.mark_non_differentiable(unused)
-            return unused, h
+            return x, h
         ctx.save_for_backward(x_new, gamma, stats)
         ctx.meta = (256, p_drop, seed, True)
         return x_new, h
@@ -524,7 +525,7 @@ class _AddLayerNorm(torch.autograd.Function):
         da = torch.empty(xn.shape, dtype=torch.bfloat16, device=xn.device) if has_a else None
         if g_h is None:
             g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
-        g_x = g_x.contiguous() if (has_a and g_x is not None) else None
+        g_x = g_x.contiguous() if g_x is not None else None
         sink = _sink_for(*ctx.params)
         dparams = None if sink is not None else torch.empty((3, 256), dtype=torch.float32, device=xn.device)
         ws = nv.add_ln_bwd(xn.data_ptr(), row_stride, g_x, g_h.contiguous(), stats[0], stats[1], gamma, dx, da, dparams, T, p_drop,
@@ -543,6 +544,36 @@ def _residual_rows(x: torch.Tensor):
     return x.contiguous(), x.shape[-1]
 
 
+class ClsLink:
+    """Joins the node that PRODUCES the residual stream entering the CLS-only last layer with the node that takes its CLS
+    rows: the gradient of those rows ([B, 1, 256]) is handed over as it is and enters the producer's backward kernel with
+    ``g_x_period`` = sequence length, instead of being scattered into a zero-filled [B, 17, 256] tensor first."""
+
+    __slots__ = ("g", "attached")
+
+    def __init__(self):
+        self.g, self.attached = None, False
+
+
+class _ClsRows(torch.autograd.Function):
+    """``x[:, :1]`` of the residual stream; with an attached ``ClsLink`` the backward passes its gradient through the link."""
+
+    @staticmethod
+    def forward(ctx, x, link):
+        ctx.link = link if (link is not None and link.attached) else None
+        ctx.shape = x.shape
+        return x[:, :1]
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.link is not None:
+            ctx.link.g = g.contiguous()
+            return None, None
+        gx = g.new_zeros(ctx.shape)
+        gx[:, :1] = g
+        return gx, None
+
+
 class _LinearAddLayerNorm(torch.autograd.Function):
     """``a = Linear(u); x_new = x + dropout(a); h = LayerNorm(x_new).bfloat16()``: the closing Linear of a sub-layer
     (out_proj / linear2) fused with ``_AddLayerNorm``.  The Linear's bias gradient (column sums of da) comes out of
@@ -550,13 +581,17 @@ class _LinearAddLayerNorm(torch.autograd.Function):
     masters weight/bias, x f32; returns (x_new, h)."""
 
     @staticmethod
-    def forward(ctx, u, weight, bias, wb, bb, x, gamma, beta, eps, p_drop, wbT=None, link=None):
+    def forward(ctx, u, weight, bias, wb, bb, x, gamma, beta, eps, p_drop, wbT=None, link=None, cls_link=None):
         from ..g2048 import native as nv
 
+        ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None, not as a zero-filled tensor
         with torch.autocast("cuda", enabled=False):
             a = F.linear(u, wb, bb)
         ctx.wbT, ctx.link = wbT, link
         ctx.params = (weight, bias, gamma, beta)
+        ctx.cls_link = cls_link
+        if cls_link is not None:
+            cls_link.attached = x.dim() == 3  # [B, S, 256]: the period of the CLS rows is S
         x, row_stride = _residual_rows(x)
         T = x.numel() // 256
         gamma, beta = gamma.contiguous(), beta.contiguous()
@@ -583,8 +618,14 @@ class _LinearAddLayerNorm(torch.autograd.Function):
         dparams = None if sink is not None else torch.empty((3, 256), dtype=torch.float32, device=xn.device)
         if g_h is None:
             g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
+        period = 1
+        cl = ctx.cls_link
+        if cl is not None and cl.g is not None:  # the stream's only gradient: the CLS rows, from _ClsRows
+            if g_x is not None:
+                raise RuntimeError("the residual stream entering the CLS-only layer has a second consumer")
+            g_x, period, cl.g = cl.g, xn.shape[1], None
         ws = nv.add_ln_bwd(xn.data_ptr(), 256, None if g_x is None else g_x.contiguous(), g_h.contiguous(), stats[0], stats[1],
-                           gamma, dx, da, dparams, T, p_drop, *seed)
+                           gamma, dx, da, dparams, T, p_drop, *seed, g_x_period=period)
         if sink is not None:
             sink.add(gamma_p, ws, 768, 256, ws.shape[0])
             sink.add(beta_p, ws[:, 256:], 768, 256, ws.shape[0])
@@ -610,9 +651,9 @@ class _LinearAddLayerNorm(torch.autograd.Function):
                     du = (da2 @ wb if du is None else du).view(u.shape)
             if sink is not None:
                 _sink_weight(sink, weight, da2, u2)
-                return du, None, None, None, None, dx, None, None, None, None, None, None
+                return du, None, None, None, None, dx, None, None, None, None, None, None, None
             dw = _SideWork.run((da2, u2), lambda: _dweight(da2, u2))
-        return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None, None
+        return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None, None, None
 
 
 class _LinearReluDropout(torch.autograd.Function):
@@ -685,8 +726,9 @@ def _fused_norm_ok(x: torch.Tensor, a) -> bool:
 def _add_norm(x: torch.Tensor, a, norm: nn.LayerNorm, p: float, training: bool):
     """(x + dropout(a), LayerNorm(x + dropout(a))); ``a`` None: (x, LayerNorm(x))."""
     if _fused_norm_ok(x, a):
-        x_new, h = _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, p if training else 0.0)
-        return (x if a is None else x_new), h
+        if a is None and _residual_rows(x)[0] is not x:  # a copy would be made: keep the caller's x as the stream
+            return x, _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, 0.0)[1]
+        return _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, p if training else 0.0)
     if a is not None:
         x = x + F.dropout(a, p, training)
     return x, F.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from ..env_definitions import BOARD_DIM
 
-from .hip_ops import (Bf16Shadow, FFNLink, _AddLayerNorm, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
+from .hip_ops import (Bf16Shadow, ClsLink, FFNLink, _AddLayerNorm, _ClsRows, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
                       _LinearAddLayerNorm, _LinearReluDropout, _LinearSplitK, _add_norm, _fused_attention_ok, _fused_norm_ok,
                       _linear, _train_bf16, graph_seed_state)
 
@@ -91,7 +91,7 @@ class TransformerEncoder(nn.Module):
         return [v[8 * i:8 * i + 8] + [self._shadow.tviews[8 * i + 6]] for i in range(len(layers))]
 
     def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor, h: torch.Tensor, next_norm,
-               cls_only: bool = False, sh=(None,) * 9):
+               cls_only: bool = False, sh=(None,) * 9, cls_link_out=None, cls_link_in=None):
         """One pre-norm encoder layer.  ``h`` = norm1(x), already computed (by the previous layer's tail); returns
         (x_out, next_norm(x_out)) so that every residual add + dropout + LayerNorm is one fused kernel
         (``_add_norm``); ``next_norm`` None: (x_out, None).  With ``cls_only`` only the CLS row of the output is
@@ -108,7 +108,7 @@ class TransformerEncoder(nn.Module):
             else:
                 q = _linear(h[:, :1], w[:D], b[:D])
                 kv = _linear(h, w[D:], b[D:])
-            x = x[:, :1]
+            x = _ClsRows.apply(x, cls_link_in) if cls_link_in is not None else x[:, :1]
             if _fused_attention_ok(kv, S, D // H):
                 a = _AttnCls.apply(q, kv, H, p)
             else:
@@ -135,7 +135,7 @@ class TransformerEncoder(nn.Module):
                 f = _linear(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7])
                 return x + F.dropout(f, p, self.training), None
             return _LinearAddLayerNorm.apply(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7], x, next_norm.weight,
-                                             next_norm.bias, next_norm.eps, p, sh[8], link)
+                                             next_norm.bias, next_norm.eps, p, sh[8], link, cls_link_out)
         a = _linear(a, attn.out_proj.weight, attn.out_proj.bias, sh[2], sh[3])
         x, h = _add_norm(x, a, layer.norm2, p, self.training)
         f = F.dropout(F.relu(_linear(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5])), p, self.training)
@@ -171,9 +171,14 @@ class TransformerEncoder(nn.Module):
         last = len(layers) - 1
         sh = self._bf16_weights(x)
         x, h = _add_norm(x, None, layers[0].norm1, 0.0, self.training)
+        # update path with a CLS-only last layer: its CLS-row gradient goes straight into the backward kernel of the layer
+        # before it (ClsLink) instead of through a zero-filled [B, 17, 256] tensor
+        cls_link = ClsLink() if (reduction == "cls" and last >= 1 and sh[0][0] is not None) else None
         for i, layer in enumerate(layers):
             x, h = self._layer(layer, x, h, layers[i + 1].norm1 if i < last else None,
-                               cls_only=(reduction == "cls" and i == last), sh=sh[i])
+                               cls_only=(reduction == "cls" and i == last), sh=sh[i],
+                               cls_link_out=cls_link if i == last - 1 else None,
+                               cls_link_in=cls_link if i == last else None)
         if self.encoder.norm is not None:
             x = self.encoder.norm(x)
         return x[:, 0, :] if reduction == "cls" else x[:, 1:, :].mean(dim=1)

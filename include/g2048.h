@@ -212,8 +212,9 @@ int g2048_attn_bwd(const void *q, const void *k, const void *v, const void *dout
 int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void *a, const float *gamma, const float *beta,
                      float *x_new, void *h, float *mean, float *rstd, int64_t T, float eps, float p_drop,
                      uint64_t seed, const uint64_t *seed_state, void *stream);
-/* x_norm = the tensor that was normalised (x_new, or x when a was NULL); g_x f32 [T][256] or NULL = gradient arriving
- * on x_new from the residual stream; g_h bf16 [T][256].  dx f32 [T][256] = g_x + dLayerNorm (gradient for x);
+/* x_norm = the tensor that was normalised (x_new, or x when a was NULL); g_x f32 or NULL = gradient arriving on x_new from
+ * the residual stream: [T][256] with g_x_period 1, or only for every g_x_period-th token row ([T / g_x_period][256], e.g.
+ * period 17 = the CLS rows of [B][17][256], all the last encoder layer hands back); g_h bf16 [T][256].  dx f32 [T][256] = g_x + dLayerNorm (gradient for x);
  * da bf16 [T][256] or NULL = dropout-masked dx (gradient for a); dparams f32 [3][256] = dgamma, dbeta and the column
  * sums of da (= the bias gradient of the Linear that produced a; zeros when da is NULL), summed in a fixed order;
  * workspace: g2048_add_ln_bwd_workspace_floats(T) floats of scratch.  dparams NULL: first stage only, the workspace then
@@ -221,7 +222,7 @@ int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void *a, const 
 int64_t g2048_add_ln_bwd_workspace_floats(int64_t T);
 int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
                      const float *rstd, const float *gamma, float *dx, void *da, float *dparams, float *workspace,
-                     int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
+                     int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, int g_x_period, void *stream);
 
 /* ---- policy network (update): bias gradients ------------------------------------------------------------ */
 

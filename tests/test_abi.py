@@ -59,7 +59,16 @@ def test_invalid_arguments_return_einval_without_touching_a_device():
     assert lib.g2048_add_ln_fwd(a, 256, None, a, a, None, a, a, a, 0, 1e-5, 0.0, 0, None, None) == -1   # T = 0
     assert lib.g2048_add_ln_fwd(a, 256, a, a, a, None, a, a, a, 4, 1e-5, 0.0, 0, None, None) == -1      # a without x_new
     assert lib.g2048_add_ln_fwd(a, 255, None, a, a, None, a, a, a, 4, 1e-5, 0.0, 0, None, None) == -1   # row stride % 4
-    assert lib.g2048_add_ln_bwd(a, 256, None, a, a, a, a, a, None, a, None, 4, 0.0, 0, None, None) == -1  # no workspace
+    assert lib.g2048_add_ln_bwd(a, 256, None, a, a, a, a, a, None, a, None, 4, 0.0, 0, None, 1, None) == -1  # no workspace
+    assert lib.g2048_add_ln_bwd(a, 256, a, a, a, a, a, a, None, a, a, 4, 0.0, 0, None, 0, None) == -1        # g_x period < 1
+    assert lib.g2048_colsum(a, 1, 2048, 4, 2048, a, None, None) == -1                         # first stage only: N <= 1024
+    assert lib.g2048_colsum_partial_rows(34816, 768) > 0 and lib.g2048_colsum_partial_rows(4, 2048) == 0
+    assert lib.g2048_linear_mask_bwd_partial_rows(34816, 1024) == 64 and lib.g2048_ffn_mask_bytes(34816, 1024) == 272 * 8 * 256 * 8
+    assert lib.g2048_linear_relu_dropout_bf16(a, 256, a, 256, None, a, 1024, 4, 256, 1024, 0.0, 0, None, None, None) == -1  # no bias
+    assert lib.g2048_linear_mask_bwd_bf16(a, 256, a, 256, None, a, 1024, a, a, 4, 256, 1024, 0.0, None) == -1  # no mask
+    assert lib.g2048_reduce_jobs(None, 3, None) == -1 and lib.g2048_reduce_jobs(None, 0, None) == 0
+    assert lib.g2048_opt_step(None, 0, a, a, a, None, 0, 0.5, None, 0, None, None, 2.0, 0.5, 2000, None, None, None) == -1
+    assert lib.g2048_opt_workspace_floats(10) >= 12
     assert lib.g2048_add_ln_bwd_workspace_floats(65) == 2 * 3 * 256
     assert lib.g2048_colsum(a, 1, 6, 4, 6, a, a, None) == -1                                  # N not a multiple of 4
     assert lib.g2048_colsum(a, 1, 512, 4, 1024, a, a, None) == -1                             # row stride < N

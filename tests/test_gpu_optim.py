@@ -230,7 +230,9 @@ def test_grad_sink_equals_per_parameter_reductions(dev, tmp_path, monkeypatch):
         a, b = g_s[n], g_n[n]
         assert torch.isfinite(a).all(), n
         err = (a - b).norm() / b.norm().clamp_min(1e-20)
-        assert err < 2e-3, (n, err.item())  # split-K slices are bf16 either way; only the order of the f32 sums differs
+        # bf16 rounding either way: 16 split-K slices rounded separately and summed in f32 (sink) vs. one bf16 GEMM output
+        # (the 2048-row GEMMs of the reference path) -- both within bf16 accuracy of the exact gradient
+        assert err < 6e-3, (n, err.item())
     # and the bucket holds exactly these values (what the optimiser kernel reads)
     for p, v in zip(tr_s._params, tr_s._flat_views):
         assert p.grad.data_ptr() == v.data_ptr()

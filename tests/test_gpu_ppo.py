@@ -310,6 +310,37 @@ def test_fused_add_layernorm_matches_torch(dev):
             else:
                 assert got[1] is None
             assert rel(got[2], gamma.grad) < 1e-4 and rel(got[3], beta.grad) < 1e-4
+    # without a branch the node passes x through as its first output: the stream's gradient and the LayerNorm gradient are
+    # added inside the backward kernel
+    base = torch.randn(5, 17, 256, device=dev).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(256, device=dev)).requires_grad_(True)
+    beta = (0.1 * torch.randn(256, device=dev)).requires_grad_(True)
+    gx, gh = torch.randn(base.shape, device=dev), torch.randn(base.shape, device=dev).to(torch.bfloat16)
+    x_out, h = _AddLayerNorm.apply(base, None, gamma, beta, 1e-5, 0.0)
+    assert torch.equal(x_out, base)
+    torch.autograd.backward([x_out, h], [gx, gh])
+    got = base.grad.clone()
+    base.grad = None
+    F.layer_norm(base, (256,), gamma, beta, 1e-5).backward(gh.float())
+    assert rel(got, base.grad + gx) < 1e-5
+    # g_x_period: a gradient for every 17th row only (the CLS rows) == the same gradient scattered into zeros
+    from src.g2048 import native as nv
+
+    B, S = 300, 17
+    xn = torch.randn(B, S, 256, device=dev)
+    g_cls = torch.randn(B, 1, 256, device=dev)
+    g_full = torch.zeros(B, S, 256, device=dev)
+    g_full[:, :1] = g_cls
+    gh = torch.randn(B, S, 256, device=dev).to(torch.bfloat16)
+    mean, var = xn.mean(-1).reshape(-1).contiguous(), xn.var(-1, unbiased=False).reshape(-1)
+    rstd = (var + 1e-5).rsqrt().contiguous()
+    outs = []
+    for g, period in ((g_full, 1), (g_cls.contiguous(), S)):
+        dx, da = torch.empty_like(xn), torch.empty(B, S, 256, device=dev, dtype=torch.bfloat16)
+        dp = torch.empty(3, 256, device=dev)
+        nv.add_ln_bwd(xn.data_ptr(), 256, g, gh, mean, rstd, gamma.detach(), dx, da, dp, B * S, 0.0, 0, 0, g_x_period=period)
+        outs.append((dx, da, dp))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
     # dropout: x_new - x is either 0 or a/(1-p); the gradient for a is masked the same way
     x = torch.zeros(4096, 17, 256, device=dev)  # so that x_new - x is exact
     a = (torch.randn(4096, 17, 256, device=dev).abs() + 0.01).to(torch.bfloat16).requires_grad_(True)

@@ -37,3 +37,12 @@ for us, c, key, shp in rows:
     tot += us
     print(f"{us:9.1f} us  {c:5.1f}x  {us / c:7.1f} us/call  {key:12s} {shp}")
 print(f"total {tot:.1f} us/minibatch")
+print("\nother aten ops by device time (self), per minibatch:")
+others = []
+for k in prof.key_averages(group_by_input_shape=True):
+    if k.key.startswith("aten::") and k.key not in ("aten::mm", "aten::addmm", "aten::bmm") and k.self_device_time_total > 0:
+        others.append((k.self_device_time_total / n, k.count / n, k.key, str(k.input_shapes)[:150]))
+others.sort(reverse=True)
+for us, c, key, shp in others[:45]:
+    print(f"{us:9.1f} us  {c:5.1f}x  {key:28s} {shp}")
+print(f"total {sum(o[0] for o in others):.1f} us/minibatch in {sum(o[1] for o in others):.0f} ops")
