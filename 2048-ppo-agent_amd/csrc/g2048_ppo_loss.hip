@@ -35,10 +35,13 @@ k_ppo_loss(const void *__restrict__ logits, int logits_bf16, const void *__restr
            const uint8_t *__restrict__ actions, const uint8_t *__restrict__ mask_bits, const float *__restrict__ old_logp,
            const float *__restrict__ adv, const float *__restrict__ ret, int64_t M, float clip_eps, float c_value,
            float c_entropy, float *__restrict__ new_logp, float *__restrict__ sums, void *__restrict__ dlogits,
-           void *__restrict__ dvalues) {
+           void *__restrict__ dvalues, const float *__restrict__ grad_scale) {
     __shared__ float red[NSUM][THREADS / 64];
     float acc[NSUM] = {0.f, 0.f, 0.f, 0.f, 0.f};  // policy, value, entropy loss, total, old - new log-prob
     const float inv_m = 1.0f / (float)M, lo = 1.0f - clip_eps, hi = 1.0f + clip_eps;
+    // gradients come out multiplied by the loss scale (GradScaler's device scalar) when one is given: what backward would
+    // otherwise do with two more launches
+    const float g_m = grad_scale ? inv_m * *grad_scale : inv_m;
     for (int64_t i = threadIdx.x; i < M; i += THREADS) {
         const uint32_t mb = mask_bits ? mask_bits[i] : 0xFu;
         float z[4], zmax = -INFINITY;
@@ -72,9 +75,9 @@ k_ppo_loss(const void *__restrict__ logits, int logits_bf16, const void *__restr
         const float g_lp = -(w1 + w2 * in_range) * A * ratio;
         for (int j = 0; j < 4; ++j) {
             const float dz = g_lp * ((j == a ? 1.0f : 0.0f) - p[j]) + c_entropy * p[j] * (lp[j] + ent);
-            st(dlogits, 4 * i + j, logits_bf16, dz * inv_m);
+            st(dlogits, 4 * i + j, logits_bf16, dz * g_m);
         }
-        st(dvalues, i, values_bf16, 2.0f * c_value * dv * inv_m);
+        st(dvalues, i, values_bf16, 2.0f * c_value * dv * g_m);
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int k = 0; k < NSUM; ++k) {
@@ -95,12 +98,12 @@ k_ppo_loss(const void *__restrict__ logits, int logits_bf16, const void *__restr
 extern "C" int g2048_ppo_loss(const void *logits, int logits_bf16, const void *values, int values_bf16, const uint8_t *actions,
                               const uint8_t *mask_bits, const float *old_logp, const float *adv, const float *ret, int64_t M,
                               float clip_eps, float c_value, float c_entropy, float *new_logp, float *sums, void *dlogits,
-                              void *dvalues, void *stream) {
+                              void *dvalues, const float *grad_scale, void *stream) {
     if (!logits || !values || !actions || !old_logp || !adv || !ret || !new_logp || !sums || !dlogits || !dvalues || M <= 0 ||
         M > G2048_PPO_LOSS_MAX_BATCH)
         return G2048_EINVAL;
     hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(THREADS), 0, (hipStream_t)stream, logits, logits_bf16, values, values_bf16, actions,
-                       mask_bits, old_logp, adv, ret, M, clip_eps, c_value, c_entropy, new_logp, sums, dlogits, dvalues);
+                       mask_bits, old_logp, adv, ret, M, clip_eps, c_value, c_entropy, new_logp, sums, dlogits, dvalues, grad_scale);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }

@@ -53,7 +53,7 @@ SIGNATURES = {
                        C.c_float, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_add_ln_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_ppo_loss": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp,
-                       _vp, _vp],
+                       _vp, _vp, _vp],
     "g2048_linear_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "g2048_ffn_mask_bytes": [_i64, _i32],
     "g2048_linear_relu_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, C.c_uint64, _vp, _vp, _vp],
@@ -435,8 +435,10 @@ def reduce_jobs(jobs):
     _check(load().g2048_reduce_jobs(C.cast(arr, _vp), len(recs), _stream()), "g2048_reduce_jobs")
 
 
-def ppo_loss(logits, values, actions, mask_bits, old_logp, adv, ret, clip_eps: float, c_value: float, c_entropy: float):
-    """-> (new_logp f32 [M], sums f32 [5], dlogits like logits, dvalues like values); see g2048_ppo_loss."""
+def ppo_loss(logits, values, actions, mask_bits, old_logp, adv, ret, clip_eps: float, c_value: float, c_entropy: float,
+             grad_scale=None):
+    """-> (new_logp f32 [M], sums f32 [5], dlogits like logits, dvalues like values); see g2048_ppo_loss.  ``grad_scale``:
+    optional device f32 scalar the two gradients are multiplied by."""
     M = actions.numel()
     for name, t in (("logits", logits), ("values", values)):
         if not t.is_cuda or t.dtype not in (torch.bfloat16, f32) or not t.is_contiguous():
@@ -450,7 +452,8 @@ def ppo_loss(logits, values, actions, mask_bits, old_logp, adv, ret, clip_eps: f
         logits.data_ptr(), int(logits.dtype == torch.bfloat16), values.data_ptr(), int(values.dtype == torch.bfloat16),
         _dev(actions, u8, M, "actions"), _dev(mask_bits, u8, M, "mask_bits", optional=True), _dev(old_logp, f32, M, "old_logp"),
         _dev(adv, f32, M, "adv"), _dev(ret, f32, M, "ret"), M, float(clip_eps), float(c_value), float(c_entropy),
-        new_logp.data_ptr(), sums.data_ptr(), dlogits.data_ptr(), dvalues.data_ptr(), _stream()), "g2048_ppo_loss")
+        new_logp.data_ptr(), sums.data_ptr(), dlogits.data_ptr(), dvalues.data_ptr(),
+        _dev(grad_scale, f32, 1, "grad_scale", optional=True), _stream()), "g2048_ppo_loss")
     return new_logp, sums, dlogits, dvalues
 
 

@@ -247,6 +247,14 @@ class FFNLink:
         self.bias_param, self.db_sunk = None, False  # linear1's bias; True when a GradSink took its gradient
 
 
+import os as _os
+
+# the wide projections of the update (in_proj 256 -> 768, the last layer's K/V 256 -> 512) through g2048_linear_bf16 instead of
+# hipBLASLt: 2.73 -> 2.69 ms per minibatch in the pipeline (isolated and cache-warm hipBLASLt is the faster one,
+# tools/probe_linear.py).  G2048_HIP_LINEAR_WIDE=0 switches back.
+_HIP_LINEAR_WIDE = _os.environ.get("G2048_HIP_LINEAR_WIDE", "1") != "0"
+
+
 def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """The first stage of ``_dweight``: bf16 [parts, out, in] whose sum over parts is dW (parts = 16 split-K slices for a
     long token axis, else 1)."""
@@ -308,7 +316,13 @@ class _LinearSplitK(torch.autograd.Function):
                 wb = weight.to(torch.bfloat16)
             if bias is not None and bb is None:
                 bb = bias.to(torch.bfloat16)
-            y = F.linear(xb, wb, bb)
+            y = None
+            if _HIP_LINEAR_WIDE and bias is not None and bias.dtype == torch.float32:
+                y = _hip_linear(xb.reshape(-1, xb.shape[-1]), wb, bias.detach())
+                if y is not None:
+                    y = y.view(*xb.shape[:-1], wb.shape[0])
+            if y is None:
+                y = F.linear(xb, wb, bb)
         ctx.save_for_backward(xb, wb)
         ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
         ctx.params = (weight, bias)
@@ -346,7 +360,13 @@ class _InProjCls(torch.autograd.Function):
         B, S, D = h.shape
         h_cls = h[:, 0].contiguous()
         q = F.linear(h_cls, wb[:D], bb[:D]).view(B, 1, D)
-        kv = F.linear(h, wb[D:], bb[D:])
+        kv = None
+        if _HIP_LINEAR_WIDE and bias.dtype == torch.float32:
+            kv = _hip_linear(h.reshape(B * S, D), wb[D:], bias.detach()[D:])
+            if kv is not None:
+                kv = kv.view(B, S, 2 * D)
+        if kv is None:
+            kv = F.linear(h, wb[D:], bb[D:])
         ctx.save_for_backward(h, h_cls, wb)
         ctx.params = (weight, bias)
         return q, kv

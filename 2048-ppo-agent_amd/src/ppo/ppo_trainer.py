@@ -75,23 +75,29 @@ class _FusedPPOLoss(torch.autograd.Function):
     """``_compute_ppo_loss`` in one HIP launch (``g2048_ppo_loss``): forward, the logged means and the gradient.
 
     -> (sums f32 [5] = mean policy, value, entropy, TOTAL loss, mean(old - new log-prob); new_log_probs [M]).
-    Only ``sums[3]`` is differentiable: backward scales the gradients the kernel already produced."""
+    Only ``sums[3]`` is differentiable: backward scales the gradients the kernel already produced.  With ``grad_scale`` (the
+    GradScaler's device scalar) the kernel itself multiplies them by it and backward passes them on untouched: the caller
+    then seeds backward with d(total) = 1 (``sums.backward(selector)``) and gets the gradients of ``grad_scale * total``,
+    i.e. ``scaler.scale(loss).backward()``, without the two scaling launches per minibatch."""
 
     @staticmethod
-    def forward(ctx, logits, values, actions_u8, mask_bits, old_lp, adv, ret, clip_eps, c_value, c_entropy):
+    def forward(ctx, logits, values, actions_u8, mask_bits, old_lp, adv, ret, clip_eps, c_value, c_entropy, grad_scale=None):
         from ..g2048 import native as nv
 
         new_lp, sums, dlogits, dvalues = nv.ppo_loss(logits.contiguous(), values.contiguous(), actions_u8, mask_bits, old_lp,
-                                                     adv, ret, clip_eps, c_value, c_entropy)
+                                                     adv, ret, clip_eps, c_value, c_entropy, grad_scale)
         ctx.save_for_backward(dlogits, dvalues)
+        ctx.prescaled = grad_scale is not None
         ctx.mark_non_differentiable(new_lp)
         return sums, new_lp
 
     @staticmethod
     def backward(ctx, g_sums, _g_new_lp):
         dlogits, dvalues = ctx.saved_tensors
-        g = g_sums[3]
-        return dlogits * g, dvalues * g, None, None, None, None, None, None, None, None
+        if ctx.prescaled:
+            return dlogits, dvalues, None, None, None, None, None, None, None, None, None
+        g = g_sums[3].to(dlogits.dtype)
+        return dlogits * g, dvalues * g.to(dvalues.dtype), None, None, None, None, None, None, None, None, None
 
 
 class _GraphedFwdBwd:
@@ -422,8 +428,8 @@ class PPOTrainer:
         return self.device.type == "cuda" and getattr(self.agent, "action_dim", 4) == 4
 
     def _loss_backward(self, obs, actions, masks, old_lp, adv, ret, cache_enabled: bool = True, zero: bool = True):
-        """Forward + loss + (scaled) backward of one minibatch -> (stats [4] f64: mean policy, value, entropy, total
-        loss; kl [1] f64), both detached.  On the device the loss, its means and its gradient are one HIP launch
+        """Forward + loss + (scaled) backward of one minibatch -> (stats [4] f32: mean policy, value, entropy, total
+        loss; kl [1] f32), both detached.  On the device the loss, its means and its gradient are one HIP launch
         (``_FusedPPOLoss``; actions/masks arrive packed, see ``_unpack_batch``), else ``_compute_ppo_loss``.
         Nothing that references the autograd graph leaves this frame: a live graph keeps the parameters'
         AccumulateGrad nodes (and the stream they were created on) alive, and a later hipGraph capture on another
@@ -434,15 +440,20 @@ class PPOTrainer:
         with ctx:
             if fused:
                 logits, values = self.agent(obs, None)
+                scale = None
+                if self.use_amp and self.scaler.is_enabled():  # the kernel applies the loss scale to its gradients
+                    if self.scaler._scale is None:
+                        self.scaler._lazy_init_scale_growth_tracker(self.device)
+                    scale = self.scaler._scale
                 sums, new_lp = _FusedPPOLoss.apply(logits, values.reshape(-1), actions,
                                                    masks if self.use_action_mask else None, old_lp, adv, ret,
-                                                   self.clip_epsilon, self.value_loss_coef, self.entropy_coef)
+                                                   self.clip_epsilon, self.value_loss_coef, self.entropy_coef, scale)
             else:
                 loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
         if zero:
             self._zero_grad()
         if fused:
-            out = self.scaler.scale(sums) if self.use_amp else sums
+            out = sums if (scale is not None or not self.use_amp) else self.scaler.scale(sums)
             # weight / bias / LayerNorm gradients: first-stage partials only, summed into the bucket by ONE launch at the end
             sink = GradSink(self._sink_targets) if (self.grad_sink and self._flat_grad is not None) else None
             with grad_sink(sink), weight_grads_on_side_stream(self.side_stream_dw):
@@ -451,9 +462,8 @@ class PPOTrainer:
                 for p, v in zip(self._params, self._flat_views):
                     if id(p) in sink.written:
                         p.grad = v
-            with torch.no_grad():
-                d = sums.detach().double()
-                return d[:4], d[4:5]
+            d = sums.detach()  # f32 [5]; the caller accumulates into f64 (one launch per use, no cast kernel)
+            return d[:4], d[4:5]
         if self.use_amp:
             self.scaler.scale(loss).backward()
         else:

@@ -247,12 +247,14 @@ int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int64_t T, int 
  * (bit a = action a legal) or NULL for no masking; old_logp, adv, ret f32 [M].
  * Out: new_logp f32 [M]; sums f32 [5] = mean policy loss, mean value loss, mean entropy loss (-H), mean total loss,
  * mean(old_logp - new_logp); dlogits [M][4] and dvalues [M] = d(mean total loss)/d(input) in the input's dtype.
- * total = policy + c_value * value + c_entropy * entropy_loss.  One workgroup, fixed summation order. */
+ * total = policy + c_value * value + c_entropy * entropy_loss.  One workgroup, fixed summation order.
+ * grad_scale (optional device f32 scalar, e.g. GradScaler's scale): dlogits and dvalues come out multiplied by it, i.e. as
+ * the gradients of grad_scale * total (scaler.scale(loss).backward() of the reference, src/ppo/ppo_trainer.py:411-413). */
 #define G2048_PPO_LOSS_MAX_BATCH 1048576
 int g2048_ppo_loss(const void *logits, int logits_bf16, const void *values, int values_bf16, const uint8_t *actions,
                    const uint8_t *mask_bits, const float *old_logp, const float *adv, const float *ret, int64_t M,
                    float clip_eps, float c_value, float c_entropy, float *new_logp, float *sums, void *dlogits,
-                   void *dvalues, void *stream);
+                   void *dvalues, const float *grad_scale, void *stream);
 
 /* ---- policy network (update): feed-forward activation ---------------------------------------------------- */
 

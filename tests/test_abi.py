@@ -80,7 +80,7 @@ def test_invalid_arguments_return_einval_without_touching_a_device():
     assert lib.g2048_embed_fwd(None, a, a, a, a, 4, 0.0, 0, None, None) == -1
     assert lib.g2048_embed_bwd(a, a, a, None, 4, 0.0, 0, None, None) == -1
     assert lib.g2048_embed_bwd_workspace_floats(4) == 256 * 32 * 256
-    assert lib.g2048_ppo_loss(a, 0, a, 0, a, None, a, a, a, 0, 0.2, 0.5, 0.01, a, a, a, a, None) == -1   # M = 0
+    assert lib.g2048_ppo_loss(a, 0, a, 0, a, None, a, a, a, 0, 0.2, 0.5, 0.01, a, a, a, a, None, None) == -1   # M = 0
     assert lib.g2048_gather_minibatch(a, 4, 0, a, a, a, a, a, a, a, a, a, a, a, a, None) == -1           # empty buffer
 
 
