@@ -285,6 +285,10 @@ int launch_stationary(const __bf16 *x, int64_t ldx, const __bf16 *w, int64_t ldw
     const int slices = N / NS;
     int64_t groups = 512 / slices;
     if (groups < 1) groups = 1;
+    // XCD locality: workgroup (x, y) has linear id x + y * groups and the dispatcher deals linear ids round-robin over the
+    // 8 XCDs, so the N-slices y of one token tile x share an XCD (and its L2 copy of the X rows) only if groups % 8 == 0.
+    // Measured with N = 768 (groups 85): 98.8 MB of HBM reads per launch for a 17.8 MB X (rocprofv3 FETCH_SIZE).
+    if (groups >= 8) groups -= groups % 8;
     if (groups > n_tiles) groups = n_tiles;
     if (groups_out) *groups_out = (int)groups;
     // the column-sum epilogue reuses the whole 64 KiB as its reduction buffer
@@ -348,6 +352,7 @@ extern "C" int64_t g2048_linear_mask_bwd_partial_rows(int64_t T, int N) {
     int64_t groups = 512 / (N / NS);
     const int64_t n_tiles = (T + TOK - 1) / TOK;
     if (groups < 1) groups = 1;
+    if (groups >= 8) groups -= groups % 8;  // as launch_stationary
     return groups > n_tiles ? n_tiles : groups;
 }
 
