@@ -94,13 +94,33 @@ k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restric
     const float4 g = reinterpret_cast<const float4 *>(gamma)[lane];
     float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0}, dsum[4] = {0, 0, 0, 0};
     const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+    // the loads of the next row are issued before this row's reductions (two dependent wave reductions per row would
+    // otherwise leave one row's 40 bytes per lane in flight)
+    struct RowIn { float4 v, gx; uint2 gb; float mean, rstd; };
+    auto fetch = [&](int64_t row) -> RowIn {
+        RowIn in;
+        in.v = reinterpret_cast<const float4 *>(xn + row * xn_rs)[lane];
+        in.gb = reinterpret_cast<const uint2 *>(g_h + row * D)[lane];
+        in.mean = mean_in[row];
+        in.rstd = rstd_in[row];
+        in.gx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_x) {
+            if (g_x_period == 1) in.gx = reinterpret_cast<const float4 *>(g_x + row * D)[lane];
+            else if (row % g_x_period == 0) in.gx = reinterpret_cast<const float4 *>(g_x + (row / g_x_period) * D)[lane];
+        }
+        return in;
+    };
+    RowIn nxt;
+    if (row0 + w < T) nxt = fetch(row0 + w);
     for (int r = w; r < ROWS_PER_BLOCK; r += WAVES) {
         const int64_t row = row0 + r;
         if (row >= T) break;
-        const float4 v = reinterpret_cast<const float4 *>(xn + row * xn_rs)[lane];
-        const uint2 gb = reinterpret_cast<const uint2 *>(g_h + row * D)[lane];
+        const RowIn cur = nxt;
+        if (r + WAVES < ROWS_PER_BLOCK && row + WAVES < T) nxt = fetch(row + WAVES);
+        const float4 v = cur.v;
+        const uint2 gb = cur.gb;
         const float gh[4] = {bf2f(gb.x & 0xFFFFu), bf2f(gb.x >> 16), bf2f(gb.y & 0xFFFFu), bf2f(gb.y >> 16)};
-        const float mean = mean_in[row], rstd = rstd_in[row];
+        const float mean = cur.mean, rstd = cur.rstd;
         const float xh[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
         const float gg[4] = {g.x, g.y, g.z, g.w};
         float dxh[4], s1sum = 0.f, s2sum = 0.f;
@@ -112,11 +132,7 @@ k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restric
             db[q] += gh[q];
         }
         const float c1 = wave_sum(s1sum) * (1.0f / D), c2 = wave_sum(s2sum) * (1.0f / D);
-        float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g_x) {
-            if (g_x_period == 1) gx = reinterpret_cast<const float4 *>(g_x + row * D)[lane];
-            else if (row % g_x_period == 0) gx = reinterpret_cast<const float4 *>(g_x + (row / g_x_period) * D)[lane];
-        }
+        const float4 gx = cur.gx;
         float o[4] = {gx.x, gx.y, gx.z, gx.w};
         for (int q = 0; q < 4; ++q) o[q] += rstd * (dxh[q] - c1 - xh[q] * c2);
         reinterpret_cast<float4 *>(dx + row * D)[lane] = make_float4(o[0], o[1], o[2], o[3]);
@@ -187,14 +203,25 @@ k_colsum_partial(const void *__restrict__ x, int64_t rs, int64_t T, int N, float
     const int cv = threadIdx.x % cols_v, rr = threadIdx.x / cols_v;
     float acc[CS_VEC] = {0.f, 0.f, 0.f, 0.f};
     if (rr < rows_per_pass) {
-        for (int64_t r = (int64_t)blockIdx.x * rows_per_pass + rr; r < T; r += (int64_t)gridDim.x * rows_per_pass) {
+        auto load = [&](int64_t r) -> float4 {
             if (BF16) {
                 const uint2 v = *reinterpret_cast<const uint2 *>((const uint16_t *)x + r * rs + CS_VEC * cv);
-                acc[0] += bf2f(v.x & 0xFFFFu); acc[1] += bf2f(v.x >> 16); acc[2] += bf2f(v.y & 0xFFFFu); acc[3] += bf2f(v.y >> 16);
-            } else {
-                const float4 v = *reinterpret_cast<const float4 *>((const float *)x + r * rs + CS_VEC * cv);
-                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                return make_float4(bf2f(v.x & 0xFFFFu), bf2f(v.x >> 16), bf2f(v.y & 0xFFFFu), bf2f(v.y >> 16));
             }
+            return *reinterpret_cast<const float4 *>((const float *)x + r * rs + CS_VEC * cv);
+        };
+        const int64_t step = (int64_t)gridDim.x * rows_per_pass;
+        int64_t r = (int64_t)blockIdx.x * rows_per_pass + rr;
+        // four rows in flight per thread (a wide matrix leaves one row per pass and workgroup: a single 8-byte load per
+        // thread and iteration reached 2.4 TB/s); the order of the additions stays fixed
+        for (; r + 3 * step < T; r += 4 * step) {
+            const float4 a = load(r), b = load(r + step), c = load(r + 2 * step), d = load(r + 3 * step);
+            acc[0] += (a.x + b.x) + (c.x + d.x); acc[1] += (a.y + b.y) + (c.y + d.y);
+            acc[2] += (a.z + b.z) + (c.z + d.z); acc[3] += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; r < T; r += step) {
+            const float4 a = load(r);
+            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
         }
     }
     for (int q = 0; q < CS_VEC; ++q) red[threadIdx.x][q] = acc[q];

@@ -253,15 +253,16 @@ import os as _os
 # hipBLASLt: 2.73 -> 2.69 ms per minibatch in the pipeline (isolated and cache-warm hipBLASLt is the faster one,
 # tools/probe_linear.py).  G2048_HIP_LINEAR_WIDE=0 switches back.
 _HIP_LINEAR_WIDE = _os.environ.get("G2048_HIP_LINEAR_WIDE", "1") != "0"
+_SINK_SLICES = int(_os.environ.get("G2048_SINK_SLICES", "16"))  # split-K slices of a weight gradient when a GradSink sums them
 
 
 def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """The first stage of ``_dweight``: bf16 [parts, out, in] whose sum over parts is dW (parts = 16 split-K slices for a
     long token axis, else 1)."""
-    T, S = x2.shape[0], _LinearSplitK.SLICES
+    T, S = x2.shape[0], _SINK_SLICES
     # also for the 2048-row GEMMs of the CLS-only layer and the heads: their [out, in] results are a handful of tiles with a
     # 2048-long reduction each (17 us per GEMM in the pipeline); the sink adds the slices at no extra launch
-    if T % S == 0 and T // S >= 128:
+    if T % S == 0 and T // S >= 64:
         return torch.bmm(dy2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1))
     return (dy2.t() @ x2).unsqueeze(0)
 
