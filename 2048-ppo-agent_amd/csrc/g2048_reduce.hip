@@ -31,6 +31,13 @@ struct JobTable {
 
 __device__ __forceinline__ float bf2f(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
 
+constexpr int RJ_WIDE8_COLS = RJ_THREADS * 8;  // 2048 columns per workgroup
+// the all-vector case of the wide shape (host and device must agree: it decides the number of workgroups of the job)
+__host__ __device__ inline bool wide8(const g2048_reduce_job &J) {
+    return J.src_bf16 && J.parts <= RJ_WIDE_MAX_PARTS && J.n % 8 == 0 && J.part_stride % 8 == 0 && !((uintptr_t)J.src & 15) &&
+           !((uintptr_t)J.dst & 15);
+}
+
 __global__ void __launch_bounds__(RJ_TX * RJ_TY)
 k_reduce_jobs(JobTable T) {
     __shared__ float red[RJ_TY][RJ_COLS + 4];
@@ -38,6 +45,27 @@ k_reduce_jobs(JobTable T) {
     int j = 0;
     while (j + 1 < T.n_jobs && (int)blockIdx.x >= T.first_block[j + 1]) ++j;  // <= 64 entries, uniform
     const g2048_reduce_job J = T.job[j];
+    if (wide8(J)) {  // bf16 slices of a weight gradient: 8 columns per thread, 16-byte loads, eight parts in flight
+        const int64_t c0 = ((int64_t)blockIdx.x - T.first_block[j]) * RJ_WIDE8_COLS + (int64_t)threadIdx.x * 8;
+        if (c0 >= J.n) return;
+        const uint16_t *src = reinterpret_cast<const uint16_t *>(J.src) + c0;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        auto add = [&](const uint4 &v) {
+            a[0] += bf2f(v.x & 0xFFFFu); a[1] += bf2f(v.x >> 16); a[2] += bf2f(v.y & 0xFFFFu); a[3] += bf2f(v.y >> 16);
+            a[4] += bf2f(v.z & 0xFFFFu); a[5] += bf2f(v.z >> 16); a[6] += bf2f(v.w & 0xFFFFu); a[7] += bf2f(v.w >> 16);
+        };
+        int p = 0;
+        for (; p + 8 <= J.parts; p += 8) {
+            uint4 v[8];
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4 *>(src + (int64_t)(p + k) * J.part_stride);
+            for (int k = 0; k < 8; ++k) add(v[k]);
+        }
+        for (; p < J.parts; ++p) add(*reinterpret_cast<const uint4 *>(src + (int64_t)p * J.part_stride));
+        float4 *dst = reinterpret_cast<float4 *>(J.dst + c0);
+        dst[0] = make_float4(a[0], a[1], a[2], a[3]);
+        dst[1] = make_float4(a[4], a[5], a[6], a[7]);
+        return;
+    }
     const bool wide = J.parts <= RJ_WIDE_MAX_PARTS;
     const int tx = wide ? (int)threadIdx.x : (int)threadIdx.x % RJ_TX, ty = wide ? 0 : (int)threadIdx.x / RJ_TX;
     const int p_step = wide ? 1 : RJ_TY;
@@ -120,7 +148,7 @@ extern "C" int g2048_reduce_jobs(const g2048_reduce_job *jobs, int n_jobs, void 
         for (int i = 0; i < T.n_jobs; ++i) {
             T.job[i] = jobs[base + i];
             T.first_block[i] = blocks;
-            const int cols = jobs[base + i].parts <= RJ_WIDE_MAX_PARTS ? RJ_WIDE_COLS : RJ_COLS;
+            const int cols = wide8(jobs[base + i]) ? RJ_WIDE8_COLS : jobs[base + i].parts <= RJ_WIDE_MAX_PARTS ? RJ_WIDE_COLS : RJ_COLS;
             blocks += (jobs[base + i].n + cols - 1) / cols;
         }
         for (int i = T.n_jobs; i <= RJ_MAX; ++i) T.first_block[i] = blocks;
