@@ -460,21 +460,36 @@ k_embed_bwd(const uint8_t *__restrict__ boards, const float *__restrict__ dx0, f
     for (int k = 0; k < EMB_CLASSES; ++k) mine[k * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t per_block = (n_rows + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * per_block, r1 = (r0 + per_block < n_rows) ? r0 + per_block : n_rows;
-    for (int64_t row = r0 + w; row < r1; row += 4) {
-        const int64_t m = row / EMB_SEQ;
-        const int c = (int)(row - m * EMB_SEQ);
-        const int k = c == 0 ? EMB_CLASSES - 1 : min((int)boards[m * 16 + c - 1], 30);
-        float4 g = reinterpret_cast<const float4 *>(dx0 + row * EMB_D)[lane];
-        if (thr && c != 0) {
-            const uint64_t base = (uint64_t)row * EMB_D + 4 * lane;
-            g.x = keep_elem(s0, s1, thr, base + 0) ? g.x * inv_keep : 0.f;
-            g.y = keep_elem(s0, s1, thr, base + 1) ? g.y * inv_keep : 0.f;
-            g.z = keep_elem(s0, s1, thr, base + 2) ? g.z * inv_keep : 0.f;
-            g.w = keep_elem(s0, s1, thr, base + 3) ? g.w * inv_keep : 0.f;
+    // four rows of this wave in flight: the read-modify-write of the LDS image is a dependent chain per row, and one 16-byte
+    // load per lane and iteration left the kernel at 1.4 TB/s
+    constexpr int PF = 4;
+    for (int64_t row = r0 + w; row < r1; row += 4 * PF) {
+        float4 g[PF];
+        int cls[PF], col[PF];
+        for (int u = 0; u < PF; ++u) {
+            const int64_t rw = row + 4 * u;
+            cls[u] = -1;
+            if (rw < r1) {
+                const int64_t m = rw / EMB_SEQ;
+                col[u] = (int)(rw - m * EMB_SEQ);
+                cls[u] = col[u] == 0 ? EMB_CLASSES - 1 : min((int)boards[m * 16 + col[u] - 1], 30);
+                g[u] = reinterpret_cast<const float4 *>(dx0 + rw * EMB_D)[lane];
+            }
         }
-        float4 a = mine[k * 64 + lane];
-        a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
-        mine[k * 64 + lane] = a;
+        for (int u = 0; u < PF; ++u) {
+            if (cls[u] < 0) break;
+            float4 gg = g[u];
+            if (thr && col[u] != 0) {
+                const uint64_t base = (uint64_t)(row + 4 * u) * EMB_D + 4 * lane;
+                gg.x = keep_elem(s0, s1, thr, base + 0) ? gg.x * inv_keep : 0.f;
+                gg.y = keep_elem(s0, s1, thr, base + 1) ? gg.y * inv_keep : 0.f;
+                gg.z = keep_elem(s0, s1, thr, base + 2) ? gg.z * inv_keep : 0.f;
+                gg.w = keep_elem(s0, s1, thr, base + 3) ? gg.w * inv_keep : 0.f;
+            }
+            float4 a = mine[cls[u] * 64 + lane];
+            a.x += gg.x; a.y += gg.y; a.z += gg.z; a.w += gg.w;
+            mine[cls[u] * 64 + lane] = a;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < EMB_CLASSES * 64; i += 256) {

@@ -104,4 +104,8 @@ class FlatAdamWStep:
             growth, backoff, interval = scaler.get_growth_factor(), scaler.get_backoff_factor(), scaler.get_growth_interval()
         nv.opt_step(table, self._n_chunks, self.grad, self.exp_avg, self.exp_avg_sq, groups, max_grad_norm, self.steps, scale,
                     tracker, growth, backoff, interval, self._ws, self.info)
+        # the kernel wrote the parameters through raw pointers: tell autograd's version counters, which is what everything
+        # that caches derived weights keys on (the bf16 shadows of the update path, the packed weights of the fused rollout
+        # encoder, torch's own saved-tensor checks).  No launch.
+        torch.autograd.graph.increment_version(self.params)
         self.optimizer._opt_called = True  # the LR scheduler checks that a step preceded scheduler.step()

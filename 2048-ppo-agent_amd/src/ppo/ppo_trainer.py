@@ -565,6 +565,11 @@ class PPOTrainer:
                 else:
                     torch.nn.utils.clip_grad_norm_(self.agent.parameters(), self.max_grad_norm)
                     self.optimizer.step()
+                if self._flat_step is None and self.device.type == "cuda":
+                    # torch's fused optimisers update the parameters without advancing autograd's version counters
+                    # (measured: an eager update kept running its forward on the bf16 shadows of the FIRST step); everything
+                    # that caches derived weights keys on them (Bf16Shadow, the fused rollout encoder's packed weights)
+                    torch.autograd.graph.increment_version(list(self.agent.parameters()))
                 self.lr_scheduler.step()
                 sums += stats
                 kl_sum += kl

@@ -89,6 +89,31 @@ def test_flat_step_matches_torch_sequence(dev, with_scaler):
         assert float(sf.get_scale()) == 1024.0 * 2 / 4 * 2  # grew after 3 clean steps, halved twice, grew again
 
 
+def test_flat_step_bumps_versions_so_cached_weights_refresh(dev, tmp_path, monkeypatch):
+    """The kernel writes parameters through raw pointers; everything that caches derived weights (bf16 shadows of the update
+    path, the packed weights of the fused rollout encoder) keys on autograd's version counters, so the step must advance
+    them: a TorchActionFunction kept across an optimiser step has to act with the NEW weights."""
+    from src.ppo import TorchActionFunction
+
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(9)
+    agent = PPOAgent(hidden_dim=512, d_model=256, nhead=8, num_layers=2, dim_feedforward=1024, dropout=0.0, reduction="cls")
+    tr = _trainer(dev, agent, tmp_path / "v", use_hip_graph=False, rollout_amp=True)
+    assert tr._flat_step is not None
+    act = TorchActionFunction(agent, use_mask=True, device=dev, amp_dtype=torch.bfloat16)
+    assert act._fused is not None
+    boards = torch.randint(0, 6, (64, 16), dtype=torch.uint8, device=dev)
+    masks = torch.full((64,), 15, dtype=torch.uint8, device=dev)
+    before, _ = act.policy_fn(boards, masks)
+    v0 = [p._version for p in agent.parameters()]
+    tr.collect_rollouts(batch_size=64, num_batches=1)
+    tr.update_policy(batch_size=256, n_epochs=1)
+    assert all(p._version > a for p, a in zip(agent.parameters(), v0))
+    after, _ = act.policy_fn(boards, masks)      # the SAME act_fn object: must have re-packed
+    fresh, _ = TorchActionFunction(agent, use_mask=True, device=dev, amp_dtype=torch.bfloat16).policy_fn(boards, masks)
+    assert torch.equal(after, fresh) and not torch.equal(after, before)
+
+
 def test_flat_step_state_dict_round_trip(dev):
     """optimizer.state_dict() of the flat step loads into a plain AdamW and back (checkpoint interchange)."""
     net_t, net_f, ot, of, st, sf, flat = _pair(dev, False)
@@ -131,7 +156,7 @@ def test_trainer_update_with_flat_step_matches_torch_step(dev, tmp_path, monkeyp
     (G2048_FLAT_OPT=0): parameters agree to f32 rounding after several optimiser steps (dropout off, eager mode)."""
     monkeypatch.chdir(tmp_path)
 
-    def run(flat):
+    def run(flat, batch, epochs):
         monkeypatch.setenv("G2048_FLAT_OPT", "1" if flat else "0")
         torch.manual_seed(5)
         agent = PPOAgent(hidden_dim=64, d_model=64, nhead=4, num_layers=2, dim_feedforward=128, dropout=0.0, reduction="cls")
@@ -139,22 +164,29 @@ def test_trainer_update_with_flat_step_matches_torch_step(dev, tmp_path, monkeyp
         assert (tr._flat_step is not None) == flat
         tr.collect_rollouts(batch_size=64, num_batches=1)
         torch.manual_seed(6)
-        m = tr.update_policy(batch_size=256, n_epochs=2)
+        m = tr.update_policy(batch_size=batch, n_epochs=epochs)
         return tr, m
 
     torch.manual_seed(5)
     init = PPOAgent(hidden_dim=64, d_model=64, nhead=4, num_layers=2, dim_feedforward=128, dropout=0.0, reduction="cls")
     p0 = torch.cat([p.detach().flatten() for p in init.parameters()]).to(dev)
-    tr_f, m_f = run(True)
-    tr_t, m_t = run(False)
+    disp = lambda tr: torch.cat([p.detach().flatten() for p in tr.agent.parameters()]) - p0
+    # ONE optimiser step (the first AdamW step moves every element by ~lr * g / (|g| + eps): elements with |g| ~ eps feel the
+    # different summation orders of the two gradient paths -- GradSink vs at::sum -- so "equal" means 2 %, not 1e-6; the
+    # arithmetic itself is pinned by test_flat_step_matches_torch_sequence on identical gradients)
+    (tr_f, m_f), (tr_t, m_t) = run(True, 1024, 1), run(False, 1024, 1)
+    assert m_f["n_updates"] == m_t["n_updates"] == 1
+    assert (disp(tr_f) - disp(tr_t)).norm() / disp(tr_t).norm() < 2e-2
+    # eight dependent steps: AdamW's m / sqrt(v) amplifies last-bit differences of the bf16 forward (an element whose
+    # gradient is near zero moves by +-lr either way), so the displacements agree as vectors, not element by element.
+    # (Both paths must run every forward on the CURRENT weights: before round 2 the eager path kept using the bf16 shadows
+    # of the first step, because torch's fused AdamW does not advance the parameters' version counters.)
+    tr_f, m_f = run(True, 256, 2)
+    tr_t, m_t = run(False, 256, 2)
     assert m_f["n_updates"] == m_t["n_updates"] >= 4
-    # element-wise equality is not to be had over several steps (AdamW's m / sqrt(v) amplifies the last-bit differences
-    # of the bf16 forward for elements whose gradient is near zero; the arithmetic itself is pinned by
-    # test_flat_step_matches_torch_sequence): the two parameter displacements must coincide as vectors
-    df = torch.cat([p.detach().flatten() for p in tr_f.agent.parameters()]) - p0
-    dt = torch.cat([p.detach().flatten() for p in tr_t.agent.parameters()]) - p0
-    assert df.norm() > 0 and (df - dt).norm() / dt.norm() < 2e-2, ((df - dt).norm() / dt.norm()).item()
-    np.testing.assert_allclose(m_f["total_loss"], m_t["total_loss"], rtol=1e-3, atol=1e-5)
+    df, dt = disp(tr_f), disp(tr_t)
+    assert df.norm() > 0 and (df - dt).norm() / dt.norm() < 0.25, ((df - dt).norm() / dt.norm()).item()
+    np.testing.assert_allclose(m_f["total_loss"], m_t["total_loss"], rtol=2e-2, atol=1e-3)
     # checkpoint written with the flat step loads into the PyTorch-step trainer and the other way round
     tr_f.save_checkpoint(str(tmp_path / "f.pt"))
     tr_t.load_checkpoint(str(tmp_path / "f.pt"), load_optimizer=True)
