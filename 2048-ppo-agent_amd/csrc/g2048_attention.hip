@@ -12,6 +12,7 @@
 // contiguous; lse f32 [B, H, Sq].  Sq = 17 (full layer) or 1 (CLS-only last layer), Sk = 17.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/g2048.h"
 
@@ -288,6 +289,243 @@ __global__ void __launch_bounds__(64) k_attn_bwd1(Params P, const uint16_t *__re
     store_row(dq + b * P.q_sb + h * HD, acc);
 }
 
+// ------------------------------------------------------------------------------------------------ Sq = 17 on MFMA
+// The 17 x 17 problems of one (sample, head) pair mapped onto v_mfma_f32_32x32x16_bf16 tiles (17 of 32 rows and columns
+// used: the matrix cores are idle either way, the point is to take the ~2700 f32 FMAs per lane off the vector ALU and the
+// K/V rows out of LDS).  One wavefront owns one sample and walks its heads; everything is computed TRANSPOSED so that a
+// lane owns one QUERY column of every tile and the softmax statistics are per lane:
+//   S^T[key][q] = K . Q^T        A = K rows (lane = key, 8 consecutive d), B = Q rows (lane = query, 8 consecutive d): both
+//                                 operands are plain 16-byte global loads, no LDS
+//   P^T         = softmax over the 16 accumulator registers of a lane + the other half-wave (lane ^ 32)
+//   O^T[d][q]   = V^T . P^T      B = P^T straight from the accumulator registers (register i of half h is key
+//                                 (i & 3) + 8 (i >> 2) + 4 h: the A operand V^T is gathered from an LDS copy of V in the
+//                                 same key order, 9 two-byte reads per lane); the result has 8 consecutive d per lane
+//                                 after one v_permlane32_swap -> 16-byte stores
+// Dropout uses the element index of the scalar kernels ((pair * 17 + q) * 32 + key), so forward and backward of either
+// implementation can be mixed.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int key_of(int i, int hf) { return (i & 3) + 8 * (i >> 2) + 4 * hf; }
+// LDS hand-over inside ONE wavefront (these kernels run 64-thread workgroups): the LDS unit executes a wave's DS instructions in
+// order, so all that is needed is that earlier DS traffic has been issued and returned before the dependent reads - not the
+// vmcnt(0) + s_barrier of __syncthreads(), which would also drain the global prefetch of the next head
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ float xhalf(float x) { return __shfl_xor(x, 32); }
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+__global__ void __launch_bounds__(64) k_attn_fwd17_mfma(Params P, uint16_t *__restrict__ o, float *__restrict__ lse) {
+    mix_seed_state(P);
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[SK * HD];  // V of the current head, [17][32] bf16
+    const int lane = threadIdx.x, r = lane & 31, hf = lane >> 5;
+    // grid = B * splits: a wavefront owns heads [h0, h1) of one sample (splits = 2 doubles the waves in flight per CU)
+    const int splits = (int)(gridDim.x / P.B);
+    const int64_t item = xcd_block(), b = item / splits;
+    const int hpw = (P.H + splits - 1) / splits, h0 = (int)(item - b * splits) * hpw, h1 = h0 + hpw < P.H ? h0 + hpw : P.H;
+    const bool row_ok = r < SK;
+    const int rr = row_ok ? r : 0;
+    const float c_log2 = P.scale * 1.4426950408889634f;
+    const bool no_drop = !(P.p_drop > 0.f);
+    const uint16_t *kb = P.k + b * P.k_sb + rr * P.k_ss + 8 * hf, *qb = P.q + b * P.q_sb + rr * P.q_ss + 8 * hf;
+    const uint16_t *vb = P.v + b * P.v_sb + (lane >> 2) * P.v_ss + 8 * (lane & 3);  // rows 0..15: one 16-byte chunk per lane
+    const uint16_t *v16 = P.v + b * P.v_sb + 16 * P.v_ss + 8 * (lane & 3);          // row 16: lanes 0..3
+    struct Op { uint4 k0, k1, q0, q1, vr, vl; };  // the operands of one head, by value (registers)
+    const uint32_t live = row_ok ? 0xFFFFFFFFu : 0u;
+    auto zpad = [&](uint4 u) { return make_uint4(u.x & live, u.y & live, u.z & live, u.w & live); };
+    auto fetch = [&](int h) -> Op {
+        Op x;
+        // unconditional loads (padding lanes read row 0 through the clamped address and are zeroed by zpad below): a load
+        // under a divergent branch gets a vmcnt(0) at the join, which serialises the prefetch
+        x.k0 = *reinterpret_cast<const uint4 *>(kb + h * HD);
+        x.k1 = *reinterpret_cast<const uint4 *>(kb + h * HD + 16);
+        x.q0 = *reinterpret_cast<const uint4 *>(qb + h * HD);
+        x.q1 = *reinterpret_cast<const uint4 *>(qb + h * HD + 16);
+        x.vr = *reinterpret_cast<const uint4 *>(vb + h * HD);
+        x.vl = *reinterpret_cast<const uint4 *>(v16 + h * HD);
+        return x;
+    };
+    Op nx;
+    if (h0 < h1) nx = fetch(h0);
+    for (int h = h0; h < h1; ++h) {
+        const int64_t pair = b * P.H + h;
+        Op c = nx;
+        c.k0 = zpad(c.k0); c.k1 = zpad(c.k1); c.q0 = zpad(c.q0); c.q1 = zpad(c.q1);
+        // ---- S^T = K Q^T
+        f32x16 st;
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) st[i] = 0.f;
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.k0), __builtin_bit_cast(bf16x8, c.q0), st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.k1), __builtin_bit_cast(bf16x8, c.q1), st, 0, 0, 0);
+        // ---- V of this head -> LDS (the previous head's reads are done: same wave, LDS is in order; barrier for the compiler)
+        wave_lds_sync();
+        *reinterpret_cast<uint4 *>(Vs + (lane >> 2) * HD + 8 * (lane & 3)) = c.vr;
+        if (lane < 4) *reinterpret_cast<uint4 *>(Vs + 16 * HD + 8 * lane) = c.vl;
+        wave_lds_sync();
+        if (h + 1 < h1) nx = fetch(h + 1);  // next head's operands in flight behind the softmax
+        // ---- softmax over the keys of this lane's query (registers 0..7 are keys < 16, register 8 of half 0 is key 16)
+        float m = -3.0e38f;
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) m = fmaxf(m, st[i]);
+        if (hf == 0) m = fmaxf(m, st[8]);
+        m = fmaxf(m, xhalf(m));
+        float p[9], l = 0.f;
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+            p[i] = exp2f((st[i] - m) * c_log2);
+            l += p[i];
+        }
+        p[8] = hf == 0 ? exp2f((st[8] - m) * c_log2) : 0.f;
+        l += p[8];
+        l += xhalf(l);
+        const float inv = P.inv_keep / l;
+        const uint64_t base = ((uint64_t)pair * SK + r) * 32;
+        _Pragma("unroll") for (int i = 0; i < 9; ++i) {
+            const bool keep = no_drop | keep_mask(P, base + key_of(i, hf));  // (bitwise: no branch per element)
+            p[i] = keep ? p[i] * inv : 0.f;
+        }
+        const uint4 pb0 = make_uint4(pack_bf16(p[0], p[1]), pack_bf16(p[2], p[3]), pack_bf16(p[4], p[5]), pack_bf16(p[6], p[7]));
+        const uint4 pb1 = make_uint4(pack_bf16(p[8], 0.f), 0u, 0u, 0u);
+        // ---- V^T in the accumulator's key order: lane = feature d
+        uint32_t w[4];
+        _Pragma("unroll") for (int j = 0; j < 8; j += 2)
+            w[j >> 1] = (uint32_t)Vs[key_of(j, hf) * HD + r] | ((uint32_t)Vs[key_of(j + 1, hf) * HD + r] << 16);
+        const uint4 va0 = make_uint4(w[0], w[1], w[2], w[3]);
+        const uint4 va1 = make_uint4(hf == 0 ? (uint32_t)Vs[16 * HD + r] : 0u, 0u, 0u, 0u);
+        // ---- O^T = V^T P^T
+        f32x16 ot;
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) ot[i] = 0.f;
+        ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va0), __builtin_bit_cast(bf16x8, pb0), ot, 0, 0, 0);
+        ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va1), __builtin_bit_cast(bf16x8, pb1), ot, 0, 0, 0);
+        // ---- lane (q, hf) holds d = key_of(i, hf): swap halves so that every lane owns 8 consecutive d, store
+        uint16_t *orow = o + ((b * SK + rr) * P.H + h) * HD + 8 * hf;
+        _Pragma("unroll") for (int mm = 0; mm < 2; ++mm) {
+            uint32_t ax = pack_bf16(ot[8 * mm + 0], ot[8 * mm + 1]), ay = pack_bf16(ot[8 * mm + 2], ot[8 * mm + 3]);
+            uint32_t bx = pack_bf16(ot[8 * mm + 4], ot[8 * mm + 5]), by = pack_bf16(ot[8 * mm + 6], ot[8 * mm + 7]);
+            const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            if (row_ok) *reinterpret_cast<uint4 *>(orow + 16 * mm) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+        if (row_ok && hf == 0) lse[pair * SK + r] = m * P.scale + __logf(l);
+    }
+}
+
+// Backward on MFMA tiles.  Two orientations of the same 17 x 17 problem, because every product wants its reduction index
+// on the operands' "k" axis and its result rows on accumulator registers:
+//   lane = QUERY column:  S^T = K Q^T, dP^T = V dO^T  ->  p, dropout, delta_q = sum_key p dp (per lane), dS^T
+//                         dQ^T[d][q] = K^T dS^T        (B = dS^T from the accumulator registers, A = K^T gathered from LDS)
+//   lane = KEY column:    S = Q K^T,  dP = dO V^T      ->  p, dropout again (lse_q and delta_q per REGISTER, from LDS), dS, P
+//                         dK^T[d][key] = Q^T dS,  dV^T[d][key] = dO^T P_dropped
+// The operand registers of Q, K, V, dO (lane = row, 8 consecutive d per half) serve as A in one orientation and as B in the
+// other; their LDS copies ([17][32] bf16 each) only feed the three transposed gathers (9 two-byte reads per lane each).
+// 14 MFMAs per (sample, head) instead of ~2700 FMAs per lane.
+__global__ void __launch_bounds__(64) k_attn_bwd17_mfma(Params P, const uint16_t *__restrict__ dout, const float *__restrict__ lse,
+                                                        uint16_t *__restrict__ dq, uint16_t *__restrict__ dk,
+                                                        uint16_t *__restrict__ dv) {
+    mix_seed_state(P);
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[SK * HD], Qs[SK * HD], Gs[SK * HD];
+    __shared__ float lseS[32], delS[32];
+    const int lane = threadIdx.x, r = lane & 31, hf = lane >> 5;
+    const int splits = (int)(gridDim.x / P.B);
+    const int64_t item = xcd_block(), b = item / splits;
+    const int hpw = (P.H + splits - 1) / splits, h0 = (int)(item - b * splits) * hpw, h1 = h0 + hpw < P.H ? h0 + hpw : P.H;
+    const bool row_ok = r < SK;
+    const int rr = row_ok ? r : 0;
+    const float c_log2 = P.scale * 1.4426950408889634f;
+    const uint16_t *kb = P.k + b * P.k_sb + rr * P.k_ss + 8 * hf, *qb = P.q + b * P.q_sb + rr * P.q_ss + 8 * hf;
+    const uint16_t *vb = P.v + b * P.v_sb + rr * P.v_ss + 8 * hf;
+    const uint16_t *gb = dout + (b * SK + rr) * P.H * HD + 8 * hf;
+    struct Op { uint4 k0, k1, q0, q1, v0, v1, g0, g1; float lq; };  // the operands of one head, by value (registers)
+    const uint32_t live = row_ok ? 0xFFFFFFFFu : 0u;
+    auto zpad = [&](uint4 u) { return make_uint4(u.x & live, u.y & live, u.z & live, u.w & live); };
+    const bool no_drop = !(P.p_drop > 0.f);
+    auto fetch = [&](int h) -> Op {
+        Op x;
+        const uint16_t *kp = kb + h * HD, *qp = qb + h * HD, *vp = vb + h * HD, *gp = gb + h * HD;
+        // unconditional loads through clamped addresses, padding lanes zeroed afterwards (see the forward kernel)
+        x.k0 = *reinterpret_cast<const uint4 *>(kp); x.k1 = *reinterpret_cast<const uint4 *>(kp + 16);
+        x.q0 = *reinterpret_cast<const uint4 *>(qp); x.q1 = *reinterpret_cast<const uint4 *>(qp + 16);
+        x.v0 = *reinterpret_cast<const uint4 *>(vp); x.v1 = *reinterpret_cast<const uint4 *>(vp + 16);
+        x.g0 = *reinterpret_cast<const uint4 *>(gp); x.g1 = *reinterpret_cast<const uint4 *>(gp + 16);
+        x.lq = lse[(b * P.H + h) * SK + rr];
+        return x;
+    };
+    struct Frag { uint4 a, b; };
+    auto mfma2 = [&](uint4 a0, uint4 a1, uint4 b0, uint4 b1) {
+        f32x16 acc;
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, b0), acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, b1), acc, 0, 0, 0);
+    };
+    // registers 0..7 of a lane are rows key_of(i, hf) < 16, register 8 of half 0 is row 16; all others are padding
+    auto gather = [&](const uint16_t *tile) -> Frag {  // tile^T in register order: lane = feature d
+        uint32_t w[4];
+        _Pragma("unroll") for (int j = 0; j < 8; j += 2) w[j >> 1] = (uint32_t)tile[key_of(j, hf) * HD + r] | ((uint32_t)tile[key_of(j + 1, hf) * HD + r] << 16);
+        return Frag{make_uint4(w[0], w[1], w[2], w[3]), make_uint4(hf == 0 ? (uint32_t)tile[16 * HD + r] : 0u, 0u, 0u, 0u)};
+    };
+    auto store_rows = [&](const f32x16 &t, uint16_t *row) {  // lane (row r, hf) of a transposed result: d = key_of(i, hf)
+        _Pragma("unroll") for (int mm = 0; mm < 2; ++mm) {
+            uint32_t ax = pack_bf16(t[8 * mm + 0], t[8 * mm + 1]), ay = pack_bf16(t[8 * mm + 2], t[8 * mm + 3]);
+            uint32_t bx = pack_bf16(t[8 * mm + 4], t[8 * mm + 5]), by = pack_bf16(t[8 * mm + 6], t[8 * mm + 7]);
+            const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            if (row_ok) *reinterpret_cast<uint4 *>(row + 16 * mm) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+    };
+#define G2048_AS_OPERAND(x) Frag{make_uint4(pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7])), \
+                                 make_uint4(pack_bf16(x[8], 0.f), 0u, 0u, 0u)}
+    Op nx;
+    if (h0 < h1) nx = fetch(h0);
+    for (int h = h0; h < h1; ++h) {
+        const int64_t pair = b * P.H + h;
+        Op c = nx;
+        c.k0 = zpad(c.k0); c.k1 = zpad(c.k1); c.q0 = zpad(c.q0); c.q1 = zpad(c.q1);
+        c.v0 = zpad(c.v0); c.v1 = zpad(c.v1); c.g0 = zpad(c.g0); c.g1 = zpad(c.g1);
+        // ---- LDS copies of K, Q, dO (row-major) for the transposed gathers; lse per query
+        wave_lds_sync();  // the previous head's gathers are done
+        if (row_ok) {
+            *reinterpret_cast<uint4 *>(Ks + r * HD + 8 * hf) = c.k0; *reinterpret_cast<uint4 *>(Ks + r * HD + 16 + 8 * hf) = c.k1;
+            *reinterpret_cast<uint4 *>(Qs + r * HD + 8 * hf) = c.q0; *reinterpret_cast<uint4 *>(Qs + r * HD + 16 + 8 * hf) = c.q1;
+            *reinterpret_cast<uint4 *>(Gs + r * HD + 8 * hf) = c.g0; *reinterpret_cast<uint4 *>(Gs + r * HD + 16 + 8 * hf) = c.g1;
+            if (hf == 0) lseS[r] = c.lq;
+        }
+        if (h + 1 < h1) nx = fetch(h + 1);  // the next head's operands travel behind this head's arithmetic
+        const float lq2 = c.lq * 1.4426950408889634f;
+        // ---- orientation 1: lane = query
+        const f32x16 st = mfma2(c.k0, c.k1, c.q0, c.q1), dpt = mfma2(c.v0, c.v1, c.g0, c.g1);
+        float ds[9], delta = 0.f;
+        {
+            const uint64_t base = ((uint64_t)pair * SK + r) * 32;
+            float p[9], dp[9];
+            _Pragma("unroll") for (int i = 0; i < 9; ++i) {
+                const bool valid = i < 8 || hf == 0;
+                const bool keep = no_drop | keep_mask(P, base + key_of(i, hf));
+                p[i] = valid ? exp2f(st[i] * c_log2 - lq2) : 0.f;
+                dp[i] = (valid && keep) ? dpt[i] * P.inv_keep : 0.f;
+                delta = fmaf(p[i], dp[i], delta);
+            }
+            delta += xhalf(delta);
+            _Pragma("unroll") for (int i = 0; i < 9; ++i) ds[i] = p[i] * (dp[i] - delta) * P.scale;
+        }
+        if (row_ok && hf == 0) delS[r] = delta;
+        wave_lds_sync();  // K/Q/dO tiles, lse and delta are in LDS
+        const Frag dsb = G2048_AS_OPERAND(ds), kt = gather(Ks);
+        store_rows(mfma2(kt.a, kt.b, dsb.a, dsb.b), dq + b * P.q_sb + rr * P.q_ss + h * HD + 8 * hf);
+        // ---- orientation 2: lane = key, register i = query key_of(i, hf)
+        const f32x16 s2 = mfma2(c.q0, c.q1, c.k0, c.k1), dp2 = mfma2(c.g0, c.g1, c.v0, c.v1);
+        float ds2[9], pd2[9];
+        _Pragma("unroll") for (int i = 0; i < 9; ++i) {
+            const bool valid = i < 8 || hf == 0;
+            const int qi = valid ? key_of(i, hf) : 0;
+            const bool keep = no_drop | keep_mask(P, ((uint64_t)pair * SK + qi) * 32 + r);
+            const float p = valid ? exp2f(s2[i] * c_log2 - lseS[qi] * 1.4426950408889634f) : 0.f;
+            const float dp = (valid && keep) ? dp2[i] * P.inv_keep : 0.f;
+            ds2[i] = p * (dp - delS[qi]) * P.scale;
+            pd2[i] = keep ? p * P.inv_keep : 0.f;
+        }
+        const Frag ds2b = G2048_AS_OPERAND(ds2), pd2b = G2048_AS_OPERAND(pd2), qt = gather(Qs), gt = gather(Gs);
+        store_rows(mfma2(qt.a, qt.b, ds2b.a, ds2b.b), dk + b * P.k_sb + rr * P.k_ss + h * HD + 8 * hf);
+        store_rows(mfma2(gt.a, gt.b, pd2b.a, pd2b.b), dv + b * P.v_sb + rr * P.v_ss + h * HD + 8 * hf);
+    }
+#undef G2048_AS_OPERAND
+}
+
 inline bool fill(Params &P, const void *q, const void *k, const void *v, int64_t B, int H, int Sq, int64_t q_sb,
                  int64_t q_ss, int64_t k_sb, int64_t k_ss, int64_t v_sb, int64_t v_ss, float scale, float p_drop,
                  uint64_t seed, const uint64_t *seed_state) {
@@ -307,6 +545,11 @@ inline int done() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }
+// G2048_ATTN_SCALAR=1 keeps the scalar 17-token kernels (read per call: no latch, no library state)
+inline bool use_mfma17() {
+    const char *e = getenv("G2048_ATTN_SCALAR");
+    return !(e && e[0] == '1');
+}
 
 }  // namespace
 
@@ -317,7 +560,10 @@ extern "C" int g2048_attn_fwd(const void *q, const void *k, const void *v, void 
     if (!o || !lse || ((uintptr_t)o & 15) || !fill(P, q, k, v, B, H, Sq, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, scale, p_drop, seed, seed_state))
         return G2048_EINVAL;
     const int64_t pairs = B * H;
-    if (Sq == SK)
+    if (Sq == SK && use_mfma17())
+        hipLaunchKernelGGL(k_attn_fwd17_mfma, dim3((unsigned)(B * (H % 2 == 0 ? 2 : 1))), dim3(64), 0, (hipStream_t)stream, P, (uint16_t *)o,
+                           lse);
+    else if (Sq == SK)
         hipLaunchKernelGGL(k_attn_fwd17, dim3((unsigned)((pairs + PAIRS - 1) / PAIRS)), dim3(64), 0, (hipStream_t)stream, P,
                            (uint16_t *)o, lse);
     else
@@ -335,7 +581,10 @@ extern "C" int g2048_attn_bwd(const void *q, const void *k, const void *v, const
         !fill(P, q, k, v, B, H, Sq, q_sb, q_ss, k_sb, k_ss, v_sb, v_ss, scale, p_drop, seed, seed_state))
         return G2048_EINVAL;
     const int64_t pairs = B * H;
-    if (Sq == SK)
+    if (Sq == SK && use_mfma17())
+        hipLaunchKernelGGL(k_attn_bwd17_mfma, dim3((unsigned)(B * (H % 2 == 0 ? 2 : 1))), dim3(64), 0, (hipStream_t)stream, P,
+                           (const uint16_t *)dout, lse, (uint16_t *)dq, (uint16_t *)dk, (uint16_t *)dv);
+    else if (Sq == SK)
         hipLaunchKernelGGL(k_attn_bwd17, dim3((unsigned)((pairs + PAIRS - 1) / PAIRS)), dim3(64), 0, (hipStream_t)stream, P,
                            (const uint16_t *)dout, lse, (uint16_t *)dq, (uint16_t *)dk, (uint16_t *)dv);
     else

@@ -267,6 +267,41 @@ def test_small_attention_kernels_match_sdpa(dev):
     assert not torch.equal(a, b)  # fresh mask per call
 
 
+def test_mfma_attention_equals_scalar_attention(dev, monkeypatch):
+    """The 17-token attention on MFMA tiles (default) vs the scalar kernels (G2048_ATTN_SCALAR=1) on the same inputs and the
+    SAME dropout seed: both use the element index (pair * 17 + query) * 32 + key for the mask, so outputs, log-sum-exps and
+    gradients agree to bf16 rounding and either forward can be paired with either backward."""
+    from src.g2048 import native as nv
+
+    H, hd, S = 8, 32, 17
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+    torch.manual_seed(3)
+    for B in (1, 7, 300, 2048):
+        for p_drop in (0.0, 0.1):
+            qkv = (torch.randn(B, S, 3 * H * hd, device=dev) * 1.5).to(torch.bfloat16)
+            do = torch.randn(B, S, H * hd, device=dev).to(torch.bfloat16)
+            W, hw = 3 * H * hd, H * hd
+            base = qkv.data_ptr()
+            res = {}
+            for impl in ("mfma", "scalar"):
+                monkeypatch.setenv("G2048_ATTN_SCALAR", "1" if impl == "scalar" else "0")
+                o = torch.empty((B, S, hw), dtype=torch.bfloat16, device=dev)
+                lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+                nv.attn_fwd(base, base + 2 * hw, base + 4 * hw, o, lse, B, H, S, (S * W, W) * 3, hd ** -0.5, p_drop, 1234, 0)
+                dqkv = torch.empty_like(qkv)
+                db = dqkv.data_ptr()
+                nv.attn_bwd(base, base + 2 * hw, base + 4 * hw, do, lse, db, db + 2 * hw, db + 4 * hw, B, H, S, (S * W, W) * 3,
+                            hd ** -0.5, p_drop, 1234, 0)
+                res[impl] = (o, lse, dqkv)
+            (o1, l1, g1), (o2, l2, g2) = res["mfma"], res["scalar"]
+            assert rel(o1, o2) < 6e-3, (B, p_drop, rel(o1, o2))
+            assert torch.allclose(l1, l2, rtol=1e-5, atol=2e-2), (l1 - l2).abs().max()  # scores from bf16 MFMA vs f32 FMAs
+            assert rel(g1, g2) < 8e-3, (B, p_drop, rel(g1, g2))
+            if p_drop > 0:  # the same entries are dropped: zeros of the attention-weighted sums cannot be compared directly,
+                # but an output row with every key dropped is exactly zero in both
+                assert torch.equal((o1 == 0).all(-1), (o2 == 0).all(-1))
+
+
 def test_fused_add_layernorm_matches_torch(dev):
     """g2048_add_ln_fwd/bwd vs torch (`x + dropout(a)` then F.layer_norm in f32, cast to bf16): values and all five
     gradients, contiguous and strided ([B, 1, 256] slice) residual input, ragged row counts; with dropout the kept
