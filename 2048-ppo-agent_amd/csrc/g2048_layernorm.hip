@@ -51,10 +51,23 @@ k_add_ln_fwd(const float *__restrict__ x, int64_t x_rs, const uint16_t *__restri
     mix_seed_state(seed_state, s0, s1);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float4 g = reinterpret_cast<const float4 *>(gamma)[lane], bt = reinterpret_cast<const float4 *>(beta)[lane];
-    for (int64_t row = (int64_t)blockIdx.x * WAVES + w; row < T; row += (int64_t)gridDim.x * WAVES) {
-        float4 v = reinterpret_cast<const float4 *>(x + row * x_rs)[lane];
+    // the next row's loads are issued before this row's two wave reductions (as in the backward kernel)
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    int64_t row = (int64_t)blockIdx.x * WAVES + w;
+    float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 an = make_uint2(0u, 0u);
+    if (row < T) {
+        vn = reinterpret_cast<const float4 *>(x + row * x_rs)[lane];
+        if (a) an = reinterpret_cast<const uint2 *>(a + row * D)[lane];
+    }
+    for (; row < T; row += stride) {
+        float4 v = vn;
+        const uint2 ab = an;
+        if (row + stride < T) {
+            vn = reinterpret_cast<const float4 *>(x + (row + stride) * x_rs)[lane];
+            if (a) an = reinterpret_cast<const uint2 *>(a + (row + stride) * D)[lane];
+        }
         if (a) {
-            const uint2 ab = reinterpret_cast<const uint2 *>(a + row * D)[lane];
             float av[4] = {bf2f(ab.x & 0xFFFFu), bf2f(ab.x >> 16), bf2f(ab.y & 0xFFFFu), bf2f(ab.y >> 16)};
             if (thr) {
                 const uint64_t base = (uint64_t)row * D + 4 * lane;
