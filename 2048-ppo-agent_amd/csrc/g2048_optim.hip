@@ -91,6 +91,34 @@ __device__ __forceinline__ void adamw1(float &p, float g, float &m, float &v, fl
     p -= step_size * m / denom;
 }
 
+// bf16 shadows of the parameters the update path multiplies with (dense copy and, for the weights whose input gradient is
+// computed by our own GEMM, a transposed copy): rewritten here, in the kernel that changes the parameter, instead of by cast
+// and transpose kernels in front of every forward
+__device__ __forceinline__ uint16_t to_bf16(float f) {
+    const __bf16 b = (__bf16)f;
+    return *reinterpret_cast<const uint16_t *>(&b);
+}
+__device__ __forceinline__ void refresh_shadow(const g2048_opt_chunk &c, int i, float a, float b, float cc, float d, int n) {
+    const float vals[4] = {a, b, cc, d};
+    const int64_t e = (int64_t)c.e0 + i;
+    if (c.shadow) {
+        uint16_t *s = reinterpret_cast<uint16_t *>(c.shadow) + e;
+        if (n == 4 && !((uintptr_t)s & 7)) {
+            *reinterpret_cast<uint2 *>(s) = make_uint2((uint32_t)to_bf16(a) | ((uint32_t)to_bf16(b) << 16),
+                                                       (uint32_t)to_bf16(cc) | ((uint32_t)to_bf16(d) << 16));
+        } else {
+            for (int q = 0; q < n; ++q) s[q] = to_bf16(vals[q]);
+        }
+    }
+    if (c.shadow_t) {
+        uint16_t *t = reinterpret_cast<uint16_t *>(c.shadow_t);
+        for (int q = 0; q < n; ++q) {
+            const int64_t eq = e + q, r = eq / c.cols, col = eq - r * c.cols;
+            t[col * c.rows + r] = to_bf16(vals[q]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(OPT_THREADS)
 k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const float *__restrict__ grads, float *__restrict__ exp_avg,
             float *__restrict__ exp_avg_sq, const float *__restrict__ partial, const Derived *__restrict__ derived, float max_grad_norm,
@@ -136,11 +164,13 @@ k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const floa
                 *reinterpret_cast<float4 *>(p + i) = pv;
                 *reinterpret_cast<float4 *>(m + i) = mv;
                 *reinterpret_cast<float4 *>(v + i) = vv;
+                if (c.shadow || c.shadow_t) refresh_shadow(c, i, pv.x, pv.y, pv.z, pv.w, 4);
             } else {
                 for (int k = i; k < c.n; ++k) {
                     float pk = p[k], mk = m[k], vk = v[k];
                     adamw1(pk, (g[k] * inv_scale) * clip, mk, vk, lr_wd, w1, b2, w2, step_size, inv_bc2_sqrt, eps);
                     p[k] = pk; m[k] = mk; v[k] = vk;
+                    if (c.shadow || c.shadow_t) refresh_shadow(c, k, pk, 0.f, 0.f, 0.f, 1);
                 }
             }
         }

@@ -539,25 +539,39 @@ OPT_MAX_GROUPS = 4  # G2048_OPT_MAX_GROUPS
 
 
 class OptChunk(C.Structure):  # g2048_opt_chunk
-    _fields_ = [("param", _vp), ("offset", _i64), ("n", C.c_int32), ("group", C.c_int32)]
+    _fields_ = [("param", _vp), ("offset", _i64), ("n", C.c_int32), ("group", C.c_int32), ("shadow", _vp), ("shadow_t", _vp),
+                ("e0", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("reserved", C.c_int32)]
+
+
+OPT_CHUNK_BYTES = C.sizeof(OptChunk)
 
 
 class OptGroup(C.Structure):  # g2048_opt_group
     _fields_ = [("lr", _dbl), ("beta1", _dbl), ("beta2", _dbl), ("eps", _dbl), ("weight_decay", _dbl)]
 
 
-def opt_chunk_table(params, offsets, groups, device) -> torch.Tensor:
+def opt_chunk_table(params, offsets, groups, device, shadows=None) -> torch.Tensor:
     """The device-resident chunk table of g2048_opt_step (u8 tensor holding g2048_opt_chunk records): parameter i (a
     contiguous f32 device tensor) has its gradient/moments at element offsets[i] of the flat buffers and belongs to
-    hyper-parameter group groups[i]."""
+    hyper-parameter group groups[i].  ``shadows``: optional {id(parameter): (bf16 copy, bf16 transposed copy or None)} the
+    step keeps up to date."""
     recs = []
+    shadows = shadows or {}
     for p, off, grp in zip(params, offsets, groups):
         if not p.is_cuda or p.dtype != f32 or not p.is_contiguous() or p.data_ptr() % 16 or off % 4:
             raise NativeError(f"opt_chunk_table: parameter {tuple(p.shape)} {p.dtype} on {p.device} (offset {off}) is not a "
                               "contiguous 16-byte aligned f32 device tensor at a flat offset that is a multiple of 4")
         n = p.numel()
+        sh, sh_t = shadows.get(id(p), (None, None))
+        for t in (sh, sh_t):
+            if t is not None and (t.dtype != torch.bfloat16 or not t.is_cuda or not t.is_contiguous() or t.numel() != n):
+                raise NativeError(f"opt_chunk_table: shadow of a {tuple(p.shape)} parameter must be a contiguous bf16 tensor of {n} elements")
+        if sh_t is not None and (p.dim() != 2 or tuple(sh_t.shape) != tuple(p.shape[::-1])):
+            raise NativeError("opt_chunk_table: a transposed shadow needs a 2-D parameter and the transposed shape")
+        rows, cols = (p.shape[0], p.shape[1]) if p.dim() == 2 else (1, max(n, 1))
         for c0 in range(0, n, OPT_CHUNK):
-            recs.append(OptChunk(p.data_ptr() + 4 * c0, off + c0, min(OPT_CHUNK, n - c0), grp))
+            recs.append(OptChunk(p.data_ptr() + 4 * c0, off + c0, min(OPT_CHUNK, n - c0), grp, sh.data_ptr() if sh is not None else None,
+                                 sh_t.data_ptr() if sh_t is not None else None, c0, rows, cols, 0))
     arr = (OptChunk * len(recs))(*recs)
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=u8)
     return host.to(device)

@@ -53,6 +53,7 @@ class FlatAdamWStep:
         self.grad_views, self.m_views, self.v_views = view(self.grad), view(self.exp_avg), view(self.exp_avg_sq)
         self.info = torch.zeros(2, dtype=torch.float32, device=self.device)  # [grad norm before clipping, found_inf]
         self._table_key, self._table, self._n_chunks, self._ws = None, None, 0, None
+        self._shadows = []  # Bf16Shadow-like objects this step keeps up to date (see adopt_shadows)
         self.adopt_state()
 
     # ------------------------------------------------------------------ state <-> torch.optim
@@ -78,11 +79,32 @@ class FlatAdamWStep:
                     self.steps[i] = float(t)
             st[p] = {"step": self.steps[i], "exp_avg": self.m_views[i], "exp_avg_sq": self.v_views[i]}
 
+    def adopt_shadows(self, shadows):
+        """Keep bf16 shadow copies of parameters up to date from inside the optimiser kernel.  ``shadows``: objects with
+        ``params`` (list), ``views`` (bf16 tensors, same order), ``tviews`` ({index: transposed bf16 tensor}), a ``key``
+        attribute and ``current_key()`` (what ``hip_ops.Bf16Shadow`` offers); only those whose parameters all belong to this
+        optimiser and whose buffers exist are taken.  Each adopted shadow is refreshed once here (a copy) and from then on by
+        ``step()``; its ``maintainer`` is set so that it stops copying on its own while its key is current."""
+        mine = {id(p) for p in self.params}
+        for sh in shadows:
+            if sh in self._shadows or getattr(sh, "views", None) is None or not all(id(p) in mine for p in sh.params):
+                continue
+            sh.key = None
+            sh()  # one eager refresh: from here on the kernel writes the same values in place
+            sh.maintainer = self
+            self._shadows.append(sh)
+            self._table_key = None  # rebuild the chunk table with the shadow pointers
+        return len(self._shadows)
+
     def _chunk_table(self):
-        key = tuple(p.data_ptr() for p in self.params)
-        if key != self._table_key:  # a parameter was re-allocated (module.to(), load with assign=True, ...)
-            self._table = nv.opt_chunk_table(self.params, self.offsets, self.group_of, self.device)
-            self._n_chunks = self._table.numel() // 24
+        key = tuple(p.data_ptr() for p in self.params) + tuple(id(sh) for sh in self._shadows)
+        if key != self._table_key:  # a parameter was re-allocated (module.to(), load with assign=True, ...) or shadows joined
+            shadow_of = {}
+            for sh in self._shadows:
+                for i, p in enumerate(sh.params):
+                    shadow_of[id(p)] = (sh.views[i], sh.tviews.get(i))
+            self._table = nv.opt_chunk_table(self.params, self.offsets, self.group_of, self.device, shadow_of)
+            self._n_chunks = self._table.numel() // nv.OPT_CHUNK_BYTES
             self._ws = nv.opt_workspace(self._n_chunks, self.device)
             self._table_key = key
         return self._table
@@ -108,4 +130,6 @@ class FlatAdamWStep:
         # that caches derived weights keys on (the bf16 shadows of the update path, the packed weights of the fused rollout
         # encoder, torch's own saved-tensor checks).  No launch.
         torch.autograd.graph.increment_version(self.params)
+        for sh in self._shadows:  # the kernel rewrote them together with the parameters: their key follows the new versions
+            sh.key = sh.current_key()
         self.optimizer._opt_called = True  # the LR scheduler checks that a step preceded scheduler.step()

@@ -25,6 +25,9 @@ class Bf16Shadow:
         self.key, self.flat, self.views = None, None, None
         self.transposed = tuple(transposed)  # indices of 2-D params that also get a [in, out] copy (``tviews[i]``)
         self.tviews = {}
+        # set by an optimiser that rewrites the shadow together with the parameters (optim.flat_step.FlatAdamWStep): the
+        # shadow then copies only when its key is stale (someone else changed a parameter), also during a hipGraph capture
+        self.maintainer = None
         Bf16Shadow._live.add(self)
 
     def invalidate(self):
@@ -35,15 +38,20 @@ class Bf16Shadow:
         """Force the next use of every shadow to re-copy (called before a hipGraph capture so that the copy becomes
         part of the graph: a replay runs no Python and would otherwise read stale shadows)."""
         for s in list(Bf16Shadow._live):
-            s.invalidate()
+            if s.maintainer is None:  # a maintained shadow is rewritten by the optimiser kernel, outside any graph
+                s.invalidate()
+
+    def current_key(self):
+        ps = self.params
+        return (ps[0].data_ptr(), sum(p._version for p in ps))
 
     def __call__(self):
         ps = self.params
-        key = (ps[0].data_ptr(), sum(p._version for p in ps))
+        key = self.current_key()
         # while a hipGraph is being captured the copy must be part of the graph whatever the key says: a replay runs no
         # Python, so a shadow that skipped the copy here (e.g. one created by copy.deepcopy / unpickling, which the
         # _live registry never saw and invalidate_all() therefore missed) would keep its capture-time weights forever
-        if key != self.key or (ps[0].is_cuda and torch.cuda.is_current_stream_capturing()):
+        if key != self.key or (self.maintainer is None and ps[0].is_cuda and torch.cuda.is_current_stream_capturing()):
             if self.flat is None or self.flat.device != ps[0].device:
                 offs, n = [], 0
                 for q in ps:

@@ -123,7 +123,9 @@ class _GraphedFwdBwd:
         torch.cuda.current_stream().wait_stream(side)
         trainer.optimizer.zero_grad(set_to_none=True)  # backward inside the capture creates the (static) gradients
         self.graph = torch.cuda.CUDAGraph()
-        Bf16Shadow.invalidate_all()  # the bf16 weight refresh must be part of the graph
+        if trainer._flat_step is not None:  # the optimiser kernel keeps the bf16 shadows current: no cast kernels in the graph
+            trainer._flat_step.adopt_shadows(list(Bf16Shadow._live))
+        Bf16Shadow.invalidate_all()  # (for the others) the bf16 weight refresh must be part of the graph
         seed_word = graph_seed_state(dev)  # allocated outside the capture
         # thread_local: only this thread's calls are checked during the capture.  Other threads (the RCCL watchdog of a
         # multi-GPU run polling its events) must not be able to invalidate it; the autograd worker's launches are
@@ -556,6 +558,7 @@ class PPOTrainer:
                     stats, kl = graphed.run(sample) if graphed is not None else self._loss_backward(**sample)
                 self._allreduce_grads()
                 if self._flat_step is not None:
+                    self._flat_step.adopt_shadows(list(Bf16Shadow._live))  # (no-op once they are adopted)
                     self._flat_step.step(self.max_grad_norm, self.scaler if self.use_amp else None)
                 elif self.use_amp:
                     self.scaler.unscale_(self.optimizer)

@@ -346,6 +346,8 @@ int g2048_reduce_jobs(const g2048_reduce_job *jobs, int n_jobs, void *stream);
  * (device memory): piece `n` <= G2048_OPT_CHUNK elements of one parameter tensor starting at `param` (16-byte aligned),
  * whose gradient and moments start at element `offset` (a multiple of 4) of the flat buffers, hyper-parameters
  * groups[group].  groups: host array, read during the call (the LR schedule changes lr every step).
+ * A chunk may name bf16 shadows of its tensor (what the bf16 update path multiplies with): they are rewritten together with
+ * the parameter, so that no cast kernels run per step.
  * max_grad_norm <= 0: no clipping.  steps: device f32 [n_steps], the number of steps taken so far, one copy per parameter
  * tensor as torch.optim keeps them (all equal; every entry +1 per non-skipped call).
  * scale / growth_tracker: the GradScaler's device scalars, or NULL/NULL when no scaler is used (then gradients are taken
@@ -356,7 +358,14 @@ int g2048_reduce_jobs(const g2048_reduce_job *jobs, int n_jobs, void *stream);
  * fixed by the chunk table. */
 #define G2048_OPT_CHUNK 2048
 #define G2048_OPT_MAX_GROUPS 4
-typedef struct { float *param; int64_t offset; int32_t n; int32_t group; } g2048_opt_chunk;
+typedef struct {
+    float *param; int64_t offset; int32_t n; int32_t group;
+    void *shadow;      /* optional bf16 copy of the tensor (dense, same element order): the chunk's piece is refreshed in place */
+    void *shadow_t;    /* optional bf16 copy of the TRANSPOSED 2-D tensor [cols][rows] */
+    int32_t e0;        /* element index of the chunk's first element inside its tensor */
+    int32_t rows, cols; /* shape of the 2-D tensor (only read when shadow_t is set) */
+    int32_t reserved;
+} g2048_opt_chunk;
 typedef struct { double lr, beta1, beta2, eps, weight_decay; } g2048_opt_group; /* f64, as torch.optim holds them */
 int64_t g2048_opt_workspace_floats(int n_chunks);
 int g2048_opt_step(const g2048_opt_chunk *chunks, int n_chunks, const float *grads, float *exp_avg, float *exp_avg_sq,

@@ -114,6 +114,45 @@ def test_flat_step_bumps_versions_so_cached_weights_refresh(dev, tmp_path, monke
     assert torch.equal(after, fresh) and not torch.equal(after, before)
 
 
+def test_optimiser_keeps_bf16_shadows_current(dev, tmp_path, monkeypatch):
+    """With the flat step the bf16 shadows of the update path (dense and transposed) are rewritten by the optimiser kernel and
+    no longer by cast kernels inside the captured graph: after several graph-replayed minibatches every shadow equals the
+    bf16 rounding of its parameter bit for bit, and so after an eager step."""
+    from src.ppo.hip_ops import Bf16Shadow
+
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(11)
+    agent = PPOAgent(hidden_dim=512, d_model=256, nhead=8, num_layers=2, dim_feedforward=1024, dropout=0.1, reduction="cls")
+    tr = _trainer(dev, agent, tmp_path / "s", rollout_amp=True, max_samples_per_epoch=6 * 1024)
+    assert tr._flat_step is not None and tr.use_hip_graph
+    tr.collect_rollouts(batch_size=128, num_batches=1)
+    m = tr.update_policy(batch_size=1024, n_epochs=1)
+    assert m["hip_graph"] and m["n_updates"] >= 3
+    mine = {id(p) for p in agent.parameters()}
+    shadows = [s for s in Bf16Shadow._live if s.views is not None and all(id(p) in mine for p in s.params)]
+    assert len(shadows) >= 2 and all(s.maintainer is tr._flat_step for s in shadows)  # encoder layers + heads
+    def check():
+        for s in shadows:
+            assert s.key == s.current_key()
+            for i, (p, v) in enumerate(zip(s.params, s.views)):
+                assert torch.equal(v, p.detach().to(torch.bfloat16)), i
+            for i, tv in s.tviews.items():
+                assert torch.equal(tv, s.params[i].detach().to(torch.bfloat16).t()), i
+    check()
+    before = [p.detach().clone() for p in agent.parameters()]
+    tr.use_hip_graph = False  # an eager minibatch takes the same optimiser path
+    tr.update_policy(batch_size=1024, n_epochs=1)
+    assert any(not torch.equal(a, b) for a, b in zip(before, agent.parameters()))
+    check()
+    # a parameter changed behind the optimiser's back (load_state_dict) makes the shadow copy again on its next use
+    with torch.no_grad():
+        agent.transformer.encoder.layers[0].linear1.weight.mul_(1.5)
+    enc = agent.transformer._shadow
+    assert enc.key != enc.current_key()
+    enc()
+    check()
+
+
 def test_flat_step_state_dict_round_trip(dev):
     """optimizer.state_dict() of the flat step loads into a plain AdamW and back (checkpoint interchange)."""
     net_t, net_f, ot, of, st, sf, flat = _pair(dev, False)
