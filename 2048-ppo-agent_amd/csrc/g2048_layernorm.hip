@@ -324,7 +324,10 @@ extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const
 // dx = the bias gradient of the Linear in front (replaces masked_scale + threshold_backward + a column-sum pass).
 namespace {
 
-constexpr int RD_THREADS = 256, RD_VEC = 8, RD_ROWS_PER_BLOCK = 64;
+constexpr int RD_THREADS = 256, RD_VEC = 8;
+// rows per workgroup: 64 for the 34 816-token activations, 8 for the 2048-row ones of the CLS-only layer (32 workgroups of 64
+// rows took 20 us for 8 MB)
+__host__ __device__ inline int rd_rows_per_block(int64_t T) { return T >= 16384 ? 64 : 8; }
 
 __global__ void __launch_bounds__(RD_THREADS)
 k_relu_dropout_fwd(const uint4 *__restrict__ x, uint4 *__restrict__ y, int64_t n_vec, float inv_keep, uint32_t thr16, uint32_t s0,
@@ -355,9 +358,10 @@ k_relu_dropout_bwd(const uint4 *__restrict__ dy, const uint4 *__restrict__ y, ui
     const int cols_v = F / RD_VEC, rows_per_pass = RD_THREADS / cols_v;
     const int cv = threadIdx.x % cols_v, rr = threadIdx.x / cols_v;
     float acc[RD_VEC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int64_t row0 = (int64_t)blockIdx.x * RD_ROWS_PER_BLOCK;
+    const int rpb = rd_rows_per_block(T);
+    const int64_t row0 = (int64_t)blockIdx.x * rpb;
     if (rr < rows_per_pass) {
-        for (int r = rr; r < RD_ROWS_PER_BLOCK; r += rows_per_pass) {
+        for (int r = rr; r < rpb; r += rows_per_pass) {
             const int64_t row = row0 + r;
             if (row >= T) break;
             const int64_t v = row * cols_v + cv;
@@ -402,7 +406,7 @@ extern "C" int g2048_relu_dropout_fwd(const void *x, void *y, int64_t T, int F, 
 }
 
 extern "C" int64_t g2048_relu_dropout_bwd_workspace_floats(int64_t T, int F) {
-    return rd_shape_ok(T, F) ? ((T + RD_ROWS_PER_BLOCK - 1) / RD_ROWS_PER_BLOCK) * F : 0;
+    return rd_shape_ok(T, F) ? ((T + rd_rows_per_block(T) - 1) / rd_rows_per_block(T)) * F : 0;
 }
 
 extern "C" int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, float *workspace, int64_t T, int F,
@@ -410,7 +414,7 @@ extern "C" int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, f
     if (!dy || !y || !dx || !workspace || !rd_shape_ok(T, F) || !(p_drop >= 0.f && p_drop < 1.f) ||
         (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)workspace) & 15))
         return G2048_EINVAL;
-    const int64_t blocks = (T + RD_ROWS_PER_BLOCK - 1) / RD_ROWS_PER_BLOCK;
+    const int64_t blocks = (T + rd_rows_per_block(T) - 1) / rd_rows_per_block(T);
     hipLaunchKernelGGL(k_relu_dropout_bwd, dim3((unsigned)blocks), dim3(RD_THREADS), 0, (hipStream_t)stream, (const uint4 *)dy,
                        (const uint4 *)y, (uint4 *)dx, workspace, T, F, 1.0f / (1.0f - p_drop));
     if (dbias)

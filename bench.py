@@ -257,6 +257,10 @@ def cpu_baseline(boards: int, total_seconds: float = 18.0):
 
 
 def main():
+    if os.environ.get("G2048_BENCH_STACKS"):  # debugging aid: dump every thread's stack to stderr every N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["G2048_BENCH_STACKS"]), repeat=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)

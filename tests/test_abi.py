@@ -74,7 +74,7 @@ def test_invalid_arguments_return_einval_without_touching_a_device():
     assert lib.g2048_colsum(a, 1, 512, 4, 1024, a, a, None) == -1                             # row stride < N
     assert lib.g2048_relu_dropout_fwd(a, a, 4, 12, 0.1, 0, None, None) == -1                  # F not a multiple of 8
     assert lib.g2048_relu_dropout_fwd(a, a, 4, 16, 1.0, 0, None, None) == -1                  # p_drop = 1
-    assert lib.g2048_relu_dropout_bwd_workspace_floats(65, 1024) == 2 * 1024
+    assert lib.g2048_relu_dropout_bwd_workspace_floats(65, 1024) == 9 * 1024 and lib.g2048_relu_dropout_bwd_workspace_floats(34816, 1024) == 544 * 1024
     assert lib.g2048_linear_bf16(a, 256, a, 256, None, a, 256, 8, 200, 256, None) == -1       # K not a multiple of 128
     assert lib.g2048_linear_bf16(a, 128, a, 256, None, a, 256, 8, 256, 256, None) == -1       # ldx < K
     assert lib.g2048_embed_fwd(None, a, a, a, a, 4, 0.0, 0, None, None) == -1
