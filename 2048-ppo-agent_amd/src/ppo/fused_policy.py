@@ -88,6 +88,11 @@ class FusedPolicy:
         # actor / critic heads: bf16 copies made once per refresh (autocast would re-cast all of them at every lock-step)
         self.heads = [[(m.weight.detach().to(torch.bfloat16), None if m.bias is None else m.bias.detach().to(torch.bfloat16))
                        for m in head if isinstance(m, torch.nn.Linear)] for head in (a.actor, a.critic)]
+        # both heads read the same features: their first layers as ONE GEMM (weights stacked), ReLU in the GEMM epilogue
+        (wa, ba), (wc, bc) = self.heads[0][0], self.heads[1][0]
+        self.head1 = None
+        if ba is not None and bc is not None and wa.shape == wc.shape:
+            self.head1 = (torch.cat([wa, wc]).t().contiguous(), torch.cat([ba, bc]), wa.shape[0])
         self.n_layers = len(t.encoder.layers)
 
     # from this many boards on, the last layer runs CLS-only in a second kernel (g2048_policy_encoder with a workspace):
@@ -119,11 +124,20 @@ class FusedPolicy:
         self.refresh_if_stale()
         feats = self.features(boards).to(torch.bfloat16)
         outs = []
-        for layers in self.heads:  # Linear-ReLU-Linear-ReLU-Linear in bf16, what autocast computes
-            x = feats
+        h1 = None
+        if self.head1 is not None:
+            w1t, b1, n1 = self.head1
+            h1 = torch._addmm_activation(b1, feats, w1t)  # relu(feats @ W^T + b), both heads, one launch
+        for k, layers in enumerate(self.heads):  # Linear-ReLU-Linear-ReLU-Linear in bf16, what autocast computes
+            x = feats if h1 is None else h1[:, k * n1:(k + 1) * n1]
             for i, (w, b) in enumerate(layers):
-                x = torch.nn.functional.linear(x, w, b)
-                if i + 1 < len(layers):
-                    x = torch.relu_(x)
+                if i == 0 and h1 is not None:
+                    continue
+                if i + 1 < len(layers) and b is not None:
+                    x = torch._addmm_activation(b, x, w.t())  # ReLU in the GEMM epilogue
+                else:
+                    x = torch.nn.functional.linear(x, w, b)
+                    if i + 1 < len(layers):
+                        x = torch.relu_(x)
             outs.append(x)
         return outs[0].float(), outs[1].float().reshape(-1)

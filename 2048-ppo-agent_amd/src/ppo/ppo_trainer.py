@@ -11,6 +11,7 @@ test are reduced globally so every rank takes the same decisions.
 from __future__ import annotations
 
 import contextlib
+import gc
 import logging
 import os
 from collections import deque
@@ -130,11 +131,22 @@ class _GraphedFwdBwd:
         # thread_local: only this thread's calls are checked during the capture.  Other threads (the RCCL watchdog of a
         # multi-GPU run polling its events) must not be able to invalidate it; the autograd worker's launches are
         # captured either way because capture is a property of the stream
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            seed_word.add_(1)  # new dropout masks on every replay (the HIP kernels read it at run time)
-            self.out = self._fwd_bwd()
-            if trainer._flat_grad is not None:
-                trainer._collect_grads(point_grads=False)  # graph-owned gradients -> all-reduce bucket, one copy
+        # No garbage collection while the stream is capturing: a collection that frees device tensors of earlier work (another
+        # trainer's graph pool, tensors last used on a side stream) makes the caching allocator issue event calls that are
+        # illegal during capture, and the process aborts (seen once in a test run, inside g2048_reduce_jobs' ctypes call, with
+        # "Garbage-collecting" on the stack).  Collect before, not during.
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                seed_word.add_(1)  # new dropout masks on every replay (the HIP kernels read it at run time)
+                self.out = self._fwd_bwd()
+                if trainer._flat_grad is not None:
+                    trainer._collect_grads(point_grads=False)  # graph-owned gradients -> all-reduce bucket, one copy
+        finally:
+            if gc_was_enabled:
+                gc.enable()
         Bf16Shadow.invalidate_all()  # nothing was copied during the capture itself
         # the gradients the replay writes (graph pool) / the tensors the optimizer reads after a replay
         self.grads = [p.grad for p in trainer.agent.parameters()]
