@@ -38,8 +38,14 @@ class Bf16Shadow:
         """Force the next use of every shadow to re-copy (called before a hipGraph capture so that the copy becomes
         part of the graph: a replay runs no Python and would otherwise read stale shadows)."""
         for s in list(Bf16Shadow._live):
-            if s.maintainer is None:  # a maintained shadow is rewritten by the optimiser kernel, outside any graph
+            if not s.maintained():  # a maintained shadow is rewritten by the optimiser kernel, outside any graph
                 s.invalidate()
+
+    def maintained(self) -> bool:
+        """An optimiser rewrites this very object's buffers (a copy.deepcopy / unpickled shadow carries the attribute of its
+        original but is not in the optimiser's list)."""
+        m = self.maintainer
+        return m is not None and any(s is self for s in getattr(m, "_shadows", ()))
 
     def current_key(self):
         ps = self.params
@@ -51,7 +57,7 @@ class Bf16Shadow:
         # while a hipGraph is being captured the copy must be part of the graph whatever the key says: a replay runs no
         # Python, so a shadow that skipped the copy here (e.g. one created by copy.deepcopy / unpickling, which the
         # _live registry never saw and invalidate_all() therefore missed) would keep its capture-time weights forever
-        if key != self.key or (self.maintainer is None and ps[0].is_cuda and torch.cuda.is_current_stream_capturing()):
+        if key != self.key or (not self.maintained() and ps[0].is_cuda and torch.cuda.is_current_stream_capturing()):
             if self.flat is None or self.flat.device != ps[0].device:
                 offs, n = [], 0
                 for q in ps:
@@ -65,7 +71,8 @@ class Bf16Shadow:
                 torch._foreach_copy_(self.views, [q.detach() for q in ps])
                 for i, tv in self.tviews.items():
                     tv.copy_(self.views[i].t())
-            self.key = key
+            # a copy recorded into a hipGraph has not run yet: leave the key stale so that the next eager use copies for real
+            self.key = None if (ps[0].is_cuda and torch.cuda.is_current_stream_capturing()) else key
         return self.views
 
 
