@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=128)
     ap.add_argument("--stop-at-2048", action="store_true", help="stop training at the first 2048 tile")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--seed", type=int, default=0, help="seed of the weights, the environments and the minibatch order")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -55,9 +56,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    torch.manual_seed(0)
+    torch.manual_seed(a.seed)
     agent = PPOAgent(**MODEL)
-    tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), OPTIM, max_steps=500000, device=dev,
+    tr = PPOTrainer(agent, BatchRunner(a.seed, device=dev), RolloutBuffer(31, 16, 4), OPTIM, max_steps=500000, device=dev,
                     rollout_amp=True, log_dir="/tmp/g2048_train_to_2048", rollout_mode=a.mode, rollout_horizon=a.horizon,
                     **TRAINER)
 
@@ -91,7 +92,10 @@ def main():
         st = tr.last_rollout_stats
         log.append({"iteration": it, "train_minutes": round(train_s / 60, 3), "timesteps": tr.total_timesteps,
                     "max_tile_in_rollout": 1 << top, "mean_episode_length": round(st["mean_episode_length"], 1),
-                    "kl": round(m["kl_divergence"], 4), "n_updates": m["n_updates"], "hip_graph": m.get("hip_graph")})
+                    "kl": round(m["kl_divergence"], 4), "n_updates": m["n_updates"], "hip_graph": m.get("hip_graph"),
+                    "policy_loss": round(m["policy_loss"], 5), "value_loss": round(m["value_loss"], 5),
+                    "entropy_loss": round(m["entropy_loss"], 5),
+                    "loss_scale": tr.scaler.get_scale() if tr.use_amp and tr.scaler.is_enabled() else None})
         if rank == 0:
             print(json.dumps(log[-1]), flush=True)
         if top >= 11 and first_2048 is None:

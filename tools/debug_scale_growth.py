@@ -1,0 +1,32 @@
+import os, sys
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "2048-ppo-agent_amd")); sys.path.insert(0, ROOT)
+import torch
+from torch.amp import GradScaler
+import bench
+from src.ppo import PPOAgent, PPOTrainer, RolloutBuffer
+from src.runs import BatchRunner
+dev = torch.device("cuda:0")
+def run(flat, graph):
+    os.environ["G2048_FLAT_OPT"] = "1" if flat else "0"
+    torch.manual_seed(0)
+    agent = PPOAgent(**bench.MODEL_CFG)
+    tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), bench.OPTIM_CFG, max_steps=500000, device=dev,
+                    rollout_amp=True, log_dir="/tmp/lg", use_hip_graph=graph, **bench.TRAINER_CFG)
+    tr.scaler = GradScaler(init_scale=65536.0, growth_interval=6)
+    tr.collect_rollouts(2048, 1)
+    tr.max_samples_per_epoch = 2048 * 30
+    out = []
+    orig = tr.lr_scheduler.step
+    prev = [torch.cat([p.detach().flatten() for p in agent.parameters()]).clone()]
+    def hook():
+        cur = torch.cat([p.detach().flatten() for p in agent.parameters()])
+        gn = float(tr._flat_step.info[0]) if tr._flat_step is not None else -1
+        out.append((round((cur - prev[0]).norm().item(), 4), float(tr.scaler.get_scale()), round(gn, 3)))
+        prev[0] = cur.clone()
+        orig()
+    tr.lr_scheduler.step = hook
+    torch.manual_seed(1)
+    tr.update_policy(batch_size=2048, n_epochs=1)
+    print("flat" if flat else "torch", "graph" if graph else "eager", out)
+run(True, True); run(False, True); run(True, False)
