@@ -268,6 +268,7 @@ import os as _os
 # hipBLASLt: 2.73 -> 2.69 ms per minibatch in the pipeline (isolated and cache-warm hipBLASLt is the faster one,
 # tools/probe_linear.py).  G2048_HIP_LINEAR_WIDE=0 switches back.
 _HIP_LINEAR_WIDE = _os.environ.get("G2048_HIP_LINEAR_WIDE", "1") != "0"
+_HEAD_RELU_FUSED = _os.environ.get("G2048_HEAD_RELU_FUSED", "1") != "0"  # Linear+ReLU of the heads as one node (_LinearRelu)
 _SINK_SLICES = int(_os.environ.get("G2048_SINK_SLICES", "16"))  # split-K slices of a weight gradient when a GradSink sums them
 
 
@@ -361,6 +362,48 @@ class _LinearSplitK(torch.autograd.Function):
                 return dx, None, None, None, None
             dw, db = _SideWork.run((dy2, x2), lambda: (_dweight(dy2, x2).to(w_dtype),
                                                        None if b_dtype is None else _colsum(dy2).to(b_dtype)))
+        return dx, dw, db, None, None
+
+
+class _LinearRelu(torch.autograd.Function):
+    """``relu(F.linear(x))`` for the hidden layers of the actor / critic heads (2048 rows per minibatch: every kernel here
+    is launch-latency-bound, so the count is what matters).  Forward: bias + ReLU in the GEMM's epilogue
+    (``torch._addmm_activation``).  Backward: threshold and the bias gradient's partial column sums in ONE launch
+    (``g2048_relu_dropout_bwd`` with p = 0, reading the saved output as the mask) instead of threshold_backward + column sum."""
+
+    @staticmethod
+    def ok(x, weight, bias, wb, bb) -> bool:
+        return (bias is not None and bias.dtype == torch.float32 and weight.dtype == torch.float32 and wb is not None
+                and bb is not None and wb.shape[0] % 8 == 0 and wb.shape[0] // 8 <= 256 and wb.is_contiguous())
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wb, bb):
+        with torch.autocast("cuda", enabled=False):
+            x2 = x.to(torch.bfloat16).reshape(-1, x.shape[-1])
+            y = torch._addmm_activation(bb, x2, wb.t())
+        ctx.save_for_backward(x2, wb, y)
+        ctx.params, ctx.meta = (weight, bias), (x.shape, x.dtype)
+        return y.view(*x.shape[:-1], wb.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ..g2048 import native as nv
+
+        x2, wb, y = ctx.saved_tensors
+        weight, bias = ctx.params
+        shape, x_dtype = ctx.meta
+        sink = _sink_for(weight, bias)
+        with torch.autocast("cuda", enabled=False):
+            dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
+            dz = torch.empty_like(y)
+            db = None if sink is not None else torch.empty(y.shape[-1], dtype=torch.float32, device=y.device)
+            ws = nv.relu_dropout_bwd(dy2, y, dz, db, 0.0)
+            dx = (dz @ wb).view(shape).to(x_dtype) if ctx.needs_input_grad[0] else None
+            if sink is not None:
+                sink.add(bias, ws, ws.shape[1], ws.shape[1], ws.shape[0])
+                _sink_weight(sink, weight, dz, x2)
+                return dx, None, None, None, None
+            dw = _SideWork.run((dz, x2), lambda: _dweight(dz, x2))
         return dx, dw, db, None, None
 
 
@@ -812,7 +855,12 @@ def _train_bf16(t: torch.Tensor, weight: torch.Tensor) -> bool:
             and torch.get_autocast_dtype("cuda") == torch.bfloat16)
 
 
-def _linear(x: torch.Tensor, weight: torch.Tensor, bias, wb=None, bb=None) -> torch.Tensor:
+def _linear(x: torch.Tensor, weight: torch.Tensor, bias, wb=None, bb=None, relu: bool = False) -> torch.Tensor:
+    """``F.linear`` (``relu``: followed by ReLU), through the update path's autograd nodes under bf16 autocast with gradients."""
     if _train_bf16(x, weight):
-        return _LinearSplitK.apply(x, weight, bias, wb, bb)
-    return F.linear(x, weight, bias)
+        if relu and _HEAD_RELU_FUSED and _LinearRelu.ok(x, weight, bias, wb, bb):
+            return _LinearRelu.apply(x, weight, bias, wb, bb)
+        y = _LinearSplitK.apply(x, weight, bias, wb, bb)
+    else:
+        y = F.linear(x, weight, bias)
+    return F.relu(y) if relu else y

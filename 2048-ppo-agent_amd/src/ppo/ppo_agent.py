@@ -49,12 +49,16 @@ class _ActorCritic(nn.Module):
         views = iter(self._head_shadow())
         outs = []
         for head in (self.actor, self.critic):
-            x = feats
-            for m in head:
+            x, mods, i = feats, list(head), 0
+            while i < len(mods):
+                m = mods[i]
                 if isinstance(m, nn.Linear):
-                    x = _linear(x, m.weight, m.bias, next(views), None if m.bias is None else next(views))
+                    relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU  # fused into the Linear's node
+                    x = _linear(x, m.weight, m.bias, next(views), None if m.bias is None else next(views), relu=relu)
+                    i += 2 if relu else 1
                 else:
                     x = m(x)
+                    i += 1
             outs.append(x)
         return outs[0], outs[1]
 

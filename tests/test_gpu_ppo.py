@@ -815,3 +815,41 @@ def test_gather_minibatch_matches_index_select(dev):
             assert torch.equal(got[k], src.index_select(0, idx)), k
         again = nv.gather_minibatch(idx.flip(0), boards, actions, masks, logp, adv, ret, out=got)
         assert again is got and torch.equal(got["obs"], boards.index_select(0, idx.flip(0)))
+
+
+def test_linear_relu_node_matches_torch(dev):
+    """``_LinearRelu`` (hidden layers of the heads): forward == relu(F.linear) in bf16 bit for bit; backward == autograd of
+    the same expression, with a GradSink (partials summed by g2048_reduce_jobs) and without."""
+    from src.ppo.hip_ops import GradSink, _LinearRelu, grad_sink
+
+    torch.manual_seed(11)
+    for T, K, N in ((2048, 256, 512), (2048, 512, 512), (300, 64, 64)):
+        w = (torch.randn(N, K, device=dev) / K ** 0.5).requires_grad_()
+        b = (torch.randn(N, device=dev) * 0.1).requires_grad_()
+        x = torch.randn(T, K, device=dev).to(torch.bfloat16).requires_grad_()
+        wb, bb = w.detach().to(torch.bfloat16), b.detach().to(torch.bfloat16)
+        g = torch.randn(T, N, device=dev).to(torch.bfloat16)
+        assert _LinearRelu.ok(x, w, b, wb, bb)
+        xr, wr, br = x.detach().clone().requires_grad_(), wb.clone().requires_grad_(), bb.clone().requires_grad_()
+        ref = torch.relu(torch.nn.functional.linear(xr, wr, br))
+        ref.backward(g)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = _LinearRelu.apply(x, w, b, wb, bb)
+        assert y.dtype == torch.bfloat16 and torch.equal(y, ref.detach())
+        y.backward(g)
+        assert torch.allclose(x.grad.float(), xr.grad.float(), rtol=2e-2, atol=2e-2)
+        # f32 weight / bias gradients: the bf16 autograd reference rounds its own to bf16
+        assert (w.grad - wr.grad.float()).norm() / wr.grad.float().norm() < 6e-3
+        assert (b.grad - br.grad.float()).norm() / br.grad.float().norm() < 6e-3
+        tw, tb = torch.zeros_like(w), torch.zeros_like(b)
+        sink = GradSink({id(w): tw, id(b): tb})
+        x2 = x.detach().clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y2 = _LinearRelu.apply(x2, w, b, wb, bb)
+        w.grad = b.grad = None
+        with grad_sink(sink):
+            y2.backward(g)
+        assert w.grad is None and b.grad is None and sink.written == {id(w), id(b)}
+        assert torch.equal(x2.grad, x.grad)
+        assert (tw - wr.grad.float()).norm() / wr.grad.float().norm() < 6e-3
+        assert (tb - br.grad.float()).norm() / br.grad.float().norm() < 6e-3

@@ -52,3 +52,17 @@ print(ka.table(sort_by="cuda_time_total", row_limit=rows, max_name_column_width=
 print("by launch count:")
 for k in sorted(ka, key=lambda k: -k.count)[:rows]:
     print(f"{k.count / n:7.1f}/mb {k.self_device_time_total / n:9.1f} us/mb  {k.key[:150]}")
+if "--timeline" in sys.argv:  # one minibatch in launch order: offset, duration, idle gap before the kernel
+    ev = sorted((e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and e.time_range is not None),
+                key=lambda e: e.time_range.start)
+    marks = [i for i, e in enumerate(ev) if "k_opt_finish" in e.name]
+    if len(marks) >= 3:
+        lo, hi = marks[len(marks) // 2 - 1] + 1, marks[len(marks) // 2] + 1
+        t0, prev_end, gaps = ev[lo].time_range.start, ev[lo].time_range.start, 0.0
+        print(f"timeline of one minibatch ({hi - lo} kernels):")
+        for e in ev[lo:hi]:
+            gap = e.time_range.start - prev_end
+            gaps += max(gap, 0.0)
+            print(f"{e.time_range.start - t0:9.1f} us  {e.time_range.end - e.time_range.start:7.1f} us  gap {gap:6.1f}  {e.name[:110]}")
+            prev_end = max(prev_end, e.time_range.end)
+        print(f"span {prev_end - t0:.1f} us, idle gaps {gaps:.1f} us")
