@@ -87,11 +87,13 @@ class _SideWork:
     Operands are kept alive until the join (the caching allocator knows nothing of the side stream's reads)."""
 
     enabled = False
+    max_rows = 0  # 0: every weight gradient; N: only those whose reduction runs over at most N rows (the CLS-only layer and the
+    #               heads: 2048 rows per minibatch, every kernel launch-latency-bound, so a parallel branch does shorten the chain)
     streams, pending, used = {}, {}, set()
 
     @classmethod
     def run(cls, keep, fn):
-        if not cls.enabled:
+        if not cls.enabled or (cls.max_rows and keep[0].shape[0] > cls.max_rows):
             return fn()
         dev = keep[0].device
         side = cls.streams.get(dev)
@@ -116,16 +118,16 @@ class weight_grads_on_side_stream:
     """Context manager around ``loss.backward()``: see ``_SideWork``.  Gradients of weights and biases are complete (on
     the current stream) when the context exits."""
 
-    def __init__(self, enabled: bool = True):
-        self.on = enabled
+    def __init__(self, enabled: bool = True, max_rows: int = 0):
+        self.on, self.max_rows = enabled, int(max_rows)
 
     def __enter__(self):
-        self.prev = _SideWork.enabled
-        _SideWork.enabled = bool(self.on)
+        self.prev = (_SideWork.enabled, _SideWork.max_rows)
+        _SideWork.enabled, _SideWork.max_rows = bool(self.on), self.max_rows
         return self
 
     def __exit__(self, *exc):
-        _SideWork.enabled = self.prev
+        _SideWork.enabled, _SideWork.max_rows = self.prev
         _SideWork.join()
         return False
 
@@ -284,7 +286,7 @@ def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
 
 
 def _sink_weight(sink, param, dy2, x2, dst_offset: int = 0):
-    parts = _dweight_parts(dy2, x2)
+    parts = _SideWork.run((dy2, x2), lambda: _dweight_parts(dy2, x2))
     n = parts.shape[1] * parts.shape[2]
     sink.add(param, parts, n, n, parts.shape[0], dst_offset)
 
@@ -301,10 +303,10 @@ def _sink_bias(sink, param, dy2, dst_offset: int = 0):
 
     N = dy2.shape[-1]
     if _colsum_sinkable(dy2):
-        ws = nv.colsum_partial(dy2)
+        ws = _SideWork.run((dy2,), lambda: nv.colsum_partial(dy2))
         sink.add(param, ws, N, N, ws.shape[0], dst_offset)
     else:  # widths the partial kernel does not take: a finished column sum, copied into place by the sink
-        sink.add(param, _colsum(dy2).contiguous(), N, N, 1, dst_offset)
+        sink.add(param, _SideWork.run((dy2,), lambda: _colsum(dy2).contiguous()), N, N, 1, dst_offset)
 
 
 def _dweight(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:

@@ -120,6 +120,8 @@ class MLPAgent(_ActorCritic):
     """MLP policy for BASELINE config 2 (the reference has none): the flattened one-hot board (16 x 31) through
     a 2-layer ReLU trunk, then the same actor/critic heads and the same call interface as PPOAgent."""
 
+    _trunk_shadow = None
+
     def __init__(self, observation_dim: int = OBS_DIM, action_dim: int = ACTION_DIM, hidden_dim: int = 512,
                  trunk_dim: int = 512, board_cells: int = 16):
         super().__init__()
@@ -134,8 +136,14 @@ class MLPAgent(_ActorCritic):
         if observations.dtype in (torch.uint8, torch.int16, torch.int32, torch.int64):
             if torch.is_grad_enabled() and self.trunk_in.weight.requires_grad:
                 oh = _one_hot(observations, self.observation_dim, self.trunk_in.weight.dtype).flatten(1)
-                h = F.relu(_linear(oh, self.trunk_in.weight, self.trunk_in.bias))
-                return F.relu(_linear(h, self.trunk_hidden.weight, self.trunk_hidden.bias))
+                ps = (self.trunk_in.weight, self.trunk_in.bias, self.trunk_hidden.weight, self.trunk_hidden.bias)
+                sh = (None,) * 4
+                if _train_bf16(oh, ps[0]):  # pre-cast bf16 shadows (kept current by the optimiser kernel), Linear+ReLU as one node
+                    if self._trunk_shadow is None:
+                        self._trunk_shadow = Bf16Shadow(list(ps))
+                    sh = self._trunk_shadow()
+                h = _linear(oh, ps[0], ps[1], sh[0], sh[1], relu=True)
+                return _linear(h, ps[2], ps[3], sh[2], sh[3], relu=True)
             # inference: one-hot @ W^T == sum over cells of the selected weight columns
             cols = observations.long() + torch.arange(self.board_cells, device=observations.device) * self.observation_dim
             h = F.embedding(cols, self.trunk_in.weight.t()).sum(dim=1) + self.trunk_in.bias
