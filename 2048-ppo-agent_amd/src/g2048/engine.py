@@ -200,7 +200,7 @@ class RolloutEngine:
     # ------------------------------------------------------------------ policy in the loop
     def rollout_policy(self, B: int, policy_fn: Callable, use_mask: bool, sample: bool = True,
                        fill_frozen: bool = False, sync_every: int = 8, B_total: Optional[int] = None,
-                       env0: int = 0, max_steps: int = 1 << 20) -> Trajectory:
+                       env0: int = 0, max_steps: int = 1 << 20, compact: bool = True) -> Trajectory:
         """B complete episodes; ``policy_fn(boards u8[B,16], masks u8[B]) -> (logits f32[B,4], values f32[B])``
         runs on the device each lock-step, sampling + env step + trajectory write are one fused kernel."""
         if B <= 0:
@@ -218,7 +218,8 @@ class RolloutEngine:
         # Policy inference only on envs that are still running (refreshed at every poll): the lock-step batch
         # keeps finished envs until the slowest one ends, but their logits are never used unless the caller
         # wants the reference's frozen frames (fill_frozen), so they are not computed.
-        compact = not fill_frozen
+        # (``compact`` False: a policy whose forward is cheaper than the two gathers and two scatters of the compaction.)
+        compact = compact and not fill_frozen
         live_idx = None
         logits_full = torch.zeros((B, 4), dtype=torch.float32, device=self.device)
         values_full = torch.zeros(B, dtype=torch.float32, device=self.device)

@@ -269,6 +269,7 @@ class PPOTrainer:
         self.grad_sink = self.device.type == "cuda" and \
             os.environ.get("G2048_GRAD_SINK", "1").strip().lower() not in ("0", "false", "no", "off")
         self._graphs = {}
+        self._rollout_graphs = {}  # captured rollout forwards of agents that ask for it (``rollout_graph_ok``: the MLP policy)
         self.hip_graph_fallback = None  # repr of the exception that made _build_graph drop to the eager update
 
         self.writer = _make_writer(log_dir) if self.rank == 0 else _NullWriter()
@@ -354,7 +355,8 @@ class PPOTrainer:
         self.rollout_buffer.reset()
         self.agent.eval()
         act = TorchActionFunction(self.agent, use_mask=self.use_action_mask, device=self.device,
-                                  amp_dtype=self.amp_dtype if self.rollout_amp else None)
+                                  amp_dtype=self.amp_dtype if self.rollout_amp else None,
+                                  graph_cache=self._rollout_graphs if getattr(self.agent, "rollout_graph_ok", False) else None)
         self.batch_runner.act_fn = act
         local_b, env0, total = self._shard(batch_size)
         self.batch_runner.env0, self.batch_runner.total_envs = env0, total

@@ -31,7 +31,7 @@ class TorchActionFunction:
 
     def __init__(self, agent, use_mask: bool = False, sample_actions: bool = True,
                  device: torch.device = torch.device("cpu"), amp_dtype: Optional[torch.dtype] = None,
-                 sync_every: int = 8, rng_mode=None, use_fused: Optional[bool] = None):
+                 sync_every: int = 8, rng_mode=None, use_fused: Optional[bool] = None, graph_cache: Optional[dict] = None):
         self.agent = agent.to(device).eval()
         self.use_mask = use_mask
         self.sample_actions = sample_actions
@@ -46,6 +46,12 @@ class TorchActionFunction:
 
             if fused_policy.supports(self.agent):
                 self._fused = fused_policy.FusedPolicy(self.agent)
+        # a cheap policy (the MLP of BASELINE configs[1]: ~15 launches of microseconds per lock-step) is launch-bound in eager
+        # mode: with a ``graph_cache`` (owned by the caller, it outlives this object) the forward over ALL boards of the batch is
+        # replayed from a hipGraph and the engine skips the live-board compaction (``compact``), whose gathers cost more than
+        # the forward they would save
+        self._graph_cache = graph_cache if (self._fused is None and torch.device(device).type == "cuda") else None
+        self.compact = self._graph_cache is None
         self._agent_params = dict(self.agent.named_parameters())
         self._agent_buffers = dict(self.agent.named_buffers())
         self._agent_state = {**self._agent_params, **self._agent_buffers}
@@ -57,6 +63,13 @@ class TorchActionFunction:
         agent_dev = next(self.agent.parameters()).device
         if self._fused is not None and boards.device == agent_dev:
             return self._fused(boards)
+        if self._graph_cache is not None and boards.device == agent_dev:
+            out = self._graphed(boards)
+            if out is not None:
+                return out
+        return self._forward(boards, agent_dev)
+
+    def _forward(self, boards, agent_dev):
         x = boards if boards.device == agent_dev else boards.to(agent_dev)
         if self.amp_dtype is not None and agent_dev.type == "cuda":
             with torch.autocast(device_type="cuda", dtype=self.amp_dtype):
@@ -64,6 +77,41 @@ class TorchActionFunction:
         else:
             logits, values = self.agent(x, None)
         return logits.float().to(boards.device), values.float().reshape(-1).to(boards.device)
+
+    def _graphed(self, boards: torch.Tensor):
+        """The forward replayed from a hipGraph (captured once per batch shape; the parameters are read in place, so later
+        optimiser steps are seen).  None: capture is not possible for this agent (remembered in the cache), run eagerly."""
+        prepare = getattr(self.agent, "prepare_rollout", None)
+        key = (tuple(boards.shape), boards.dtype, self.amp_dtype, next(self.agent.parameters()).data_ptr())
+        entry = self._graph_cache.get(key, False)
+        if entry is False:
+            entry = None
+            try:
+                if prepare is not None:
+                    prepare()  # (before the capture: the refresh must not become part of the graph)
+                static_in = torch.empty_like(boards)
+                static_in.copy_(boards)
+                side = torch.cuda.Stream(device=boards.device)
+                side.wait_stream(torch.cuda.current_stream(boards.device))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._forward(static_in, boards.device)
+                torch.cuda.current_stream(boards.device).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    out = self._forward(static_in, boards.device)
+                entry = (graph, static_in, out)
+            except Exception as e:  # not capturable: eager from now on (the reason stays visible in the cache)
+                self._graph_cache["fallback"] = repr(e)
+            self._graph_cache[key] = entry
+        if entry is None:
+            return None
+        graph, static_in, out = entry
+        if prepare is not None:
+            prepare()
+        static_in.copy_(boards)
+        graph.replay()
+        return out
 
     @torch.no_grad()
     def __call__(self, rng_key, obs, mask):

@@ -97,7 +97,8 @@ class BatchRunner:
             return self._engine.rollout_fused(B, fused, **kw)
         if hasattr(fn, "policy_fn"):  # TorchActionFunction
             return self._engine.rollout_policy(B, fn.policy_fn, use_mask=fn.use_mask, sample=fn.sample_actions,
-                                               sync_every=getattr(fn, "sync_every", 8), **kw)
+                                               sync_every=getattr(fn, "sync_every", 8), compact=getattr(fn, "compact", True),
+                                               **kw)
         return self._collect_host_callable(B, fn, fill_frozen)
 
     def collect_fixed(self, batch_size: int, horizon: int, restart: bool = False):

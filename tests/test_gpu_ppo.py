@@ -853,3 +853,38 @@ def test_linear_relu_node_matches_torch(dev):
         assert torch.equal(x2.grad, x.grad)
         assert (tw - wr.grad.float()).norm() / wr.grad.float().norm() < 6e-3
         assert (tb - br.grad.float()).norm() / br.grad.float().norm() < 6e-3
+
+
+def test_graphed_rollout_forward_of_the_mlp_policy(dev, tmp_path, monkeypatch):
+    """The MLP policy's rollout forward replayed from a hipGraph (TorchActionFunction(graph_cache=...)): same logits/values
+    as the eager forward, in-place parameter updates are seen by the replay, the engine then runs without compaction, and
+    the trainer's collect uses it (one capture, reused by the next collect)."""
+    torch.manual_seed(5)
+    agent = MLPAgent().to(dev)
+    cache = {}
+    fn = TorchActionFunction(agent, use_mask=True, device=dev, amp_dtype=torch.bfloat16, graph_cache=cache)
+    assert fn.compact is False
+    boards = torch.randint(0, 12, (4096, 16), dtype=torch.uint8, device=dev)
+    ref = TorchActionFunction(agent, use_mask=True, device=dev, amp_dtype=torch.bfloat16)
+    assert ref.compact is True
+    lg, vl = (t.clone() for t in fn.policy_fn(boards, None))  # (the graph's static outputs: overwritten by the next call)
+    assert "fallback" not in cache and len(cache) == 1
+    lr, vr = ref.policy_fn(boards, None)
+    assert torch.equal(lg, lr) and torch.equal(vl, vr)
+    boards2 = torch.randint(0, 12, (4096, 16), dtype=torch.uint8, device=dev)
+    with torch.no_grad():
+        for p in agent.parameters():
+            p.mul_(0.5)
+    lg2, vl2 = fn.policy_fn(boards2, None)
+    lr2, vr2 = ref.policy_fn(boards2, None)
+    assert len(cache) == 1 and torch.equal(lg2, lr2) and torch.equal(vl2, vr2) and not torch.equal(lg2, lg)
+    # through the trainer: the capture happens in the first collect and is reused by the second
+    monkeypatch.chdir(tmp_path)
+    tr = PPOTrainer(MLPAgent(), BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), OPTIM, max_steps=100, device=dev,
+                    rollout_amp=True, use_action_mask=True, max_samples_per_epoch=4096, log_dir=str(tmp_path / "lg"))
+    tr.collect_rollouts(512, 1)
+    assert len(tr._rollout_graphs) == 1 and "fallback" not in tr._rollout_graphs
+    n1 = tr.rollout_buffer.buffer_size
+    tr.update_policy(batch_size=256, n_epochs=1)
+    tr.collect_rollouts(512, 1)
+    assert len(tr._rollout_graphs) == 1 and n1 > 512 and tr.rollout_buffer.buffer_size > 512

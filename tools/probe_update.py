@@ -16,7 +16,8 @@ from src.runs import BatchRunner
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-agent = PPOAgent(**bench.MODEL_CFG)
+from src.ppo import MLPAgent
+agent = MLPAgent() if "--mlp" in sys.argv else PPOAgent(**bench.MODEL_CFG)
 tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), bench.OPTIM_CFG, max_steps=500000, device=dev,
                 rollout_amp=True, log_dir="/tmp/lg", **bench.TRAINER_CFG)
 tr.collect_rollouts(8192, 1)
