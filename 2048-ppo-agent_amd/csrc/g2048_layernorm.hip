@@ -50,7 +50,11 @@ k_add_ln_fwd(const float *__restrict__ x, int64_t x_rs, const uint16_t *__restri
              uint32_t thr, uint32_t s0, uint32_t s1, const uint64_t *seed_state) {
     mix_seed_state(seed_state, s0, s1);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const float4 g = reinterpret_cast<const float4 *>(gamma)[lane], bt = reinterpret_cast<const float4 *>(beta)[lane];
+    // gamma NULL: no LayerNorm, h = bf16(x + dropout(a)) (the last sub-layer of the encoder: its output feeds the heads in bf16)
+    const bool norm = gamma != nullptr;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g = norm ? reinterpret_cast<const float4 *>(gamma)[lane] : zero4;
+    const float4 bt = norm ? reinterpret_cast<const float4 *>(beta)[lane] : zero4;
     // the next row's loads are issued before this row's two wave reductions (as in the backward kernel)
     const int64_t stride = (int64_t)gridDim.x * WAVES;
     int64_t row = (int64_t)blockIdx.x * WAVES + w;
@@ -74,7 +78,11 @@ k_add_ln_fwd(const float *__restrict__ x, int64_t x_rs, const uint16_t *__restri
                 for (int q = 0; q < 4; ++q) av[q] = keep_elem(s0, s1, thr, base + q) ? av[q] * inv_keep : 0.0f;
             }
             v.x += av[0]; v.y += av[1]; v.z += av[2]; v.w += av[3];
-            reinterpret_cast<float4 *>(x_new + row * D)[lane] = v;
+            if (x_new) reinterpret_cast<float4 *>(x_new + row * D)[lane] = v;
+        }
+        if (!norm) {
+            reinterpret_cast<uint2 *>(h + row * D)[lane] = make_uint2(f2bf(v.x) | (f2bf(v.y) << 16), f2bf(v.z) | (f2bf(v.w) << 16));
+            continue;
         }
         const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / D);
         const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
@@ -104,7 +112,8 @@ k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restric
     mix_seed_state(seed_state, s0, s1);
     __shared__ float red[WAVES][3][D];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const float4 g = reinterpret_cast<const float4 *>(gamma)[lane];
+    const bool norm = gamma != nullptr;  // NULL: the forward had no LayerNorm (h = bf16(x_new)): dx = g_x + g_h
+    const float4 g = norm ? reinterpret_cast<const float4 *>(gamma)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0}, dsum[4] = {0, 0, 0, 0};
     const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
     // the loads of the next row are issued before this row's reductions (two dependent wave reductions per row would
@@ -112,10 +121,14 @@ k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restric
     struct RowIn { float4 v, gx; uint2 gb; float mean, rstd; };
     auto fetch = [&](int64_t row) -> RowIn {
         RowIn in;
-        in.v = reinterpret_cast<const float4 *>(xn + row * xn_rs)[lane];
+        in.v = make_float4(0.f, 0.f, 0.f, 0.f);
+        in.mean = in.rstd = 0.f;
+        if (norm) {  // (uniform)
+            in.v = reinterpret_cast<const float4 *>(xn + row * xn_rs)[lane];
+            in.mean = mean_in[row];
+            in.rstd = rstd_in[row];
+        }
         in.gb = reinterpret_cast<const uint2 *>(g_h + row * D)[lane];
-        in.mean = mean_in[row];
-        in.rstd = rstd_in[row];
         in.gx = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g_x) {
             if (g_x_period == 1) in.gx = reinterpret_cast<const float4 *>(g_x + row * D)[lane];
@@ -144,10 +157,14 @@ k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restric
             dg[q] += gh[q] * xh[q];
             db[q] += gh[q];
         }
-        const float c1 = wave_sum(s1sum) * (1.0f / D), c2 = wave_sum(s2sum) * (1.0f / D);
         const float4 gx = cur.gx;
         float o[4] = {gx.x, gx.y, gx.z, gx.w};
-        for (int q = 0; q < 4; ++q) o[q] += rstd * (dxh[q] - c1 - xh[q] * c2);
+        if (norm) {
+            const float c1 = wave_sum(s1sum) * (1.0f / D), c2 = wave_sum(s2sum) * (1.0f / D);
+            for (int q = 0; q < 4; ++q) o[q] += rstd * (dxh[q] - c1 - xh[q] * c2);
+        } else {
+            for (int q = 0; q < 4; ++q) o[q] += gh[q];
+        }
         reinterpret_cast<float4 *>(dx + row * D)[lane] = make_float4(o[0], o[1], o[2], o[3]);
         if (da) {
             if (thr) {
@@ -186,7 +203,7 @@ inline int done() {
 extern "C" int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void *a, const float *gamma, const float *beta,
                                 float *x_new, void *h, float *mean, float *rstd, int64_t T, float eps, float p_drop,
                                 uint64_t seed, const uint64_t *seed_state, void *stream) {
-    if (!x || !gamma || !beta || !h || !mean || !rstd || T <= 0 || (a && !x_new) || !(p_drop >= 0.f && p_drop < 1.f) ||
+    if (!x || !h || T <= 0 || (gamma && (!beta || !mean || !rstd || (a && !x_new))) || !(p_drop >= 0.f && p_drop < 1.f) ||
         (x_row_stride & 3) || (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)x_new) & 15) ||
         (((uintptr_t)a | (uintptr_t)h) & 7))
         return G2048_EINVAL;
@@ -303,7 +320,7 @@ extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const
                                 const float *rstd, const float *gamma, float *dx, void *da, float *dparams, float *workspace,
                                 int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, int g_x_period, void *stream) {
     if (g_x_period < 1) return G2048_EINVAL;
-    if (!x_norm || !g_h || !mean || !rstd || !gamma || !dx || !workspace || T <= 0 || (x_row_stride & 3) ||
+    if (!g_h || !dx || !workspace || T <= 0 || (x_row_stride & 3) || (gamma && (!x_norm || !mean || !rstd)) ||
         !(p_drop >= 0.f && p_drop < 1.f) || (((uintptr_t)x_norm | (uintptr_t)g_x | (uintptr_t)dx | (uintptr_t)gamma) & 15) ||
         (((uintptr_t)g_h | (uintptr_t)da) & 7))
         return G2048_EINVAL;

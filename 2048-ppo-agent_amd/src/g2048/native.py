@@ -339,24 +339,27 @@ def attn_bwd(q_ptr: int, k_ptr: int, v_ptr: int, dout, lse, dq_ptr: int, dk_ptr:
 
 def add_ln_fwd(x_ptr: int, x_row_stride: int, a, gamma, beta, x_new, h, mean, rstd, T: int, eps: float, p_drop: float,
                seed: int, seed_state: int = 0):
-    """x_ptr: raw device address of f32 rows (stride x_row_stride elements) the caller keeps alive."""
+    """x_ptr: raw device address of f32 rows (stride x_row_stride elements) the caller keeps alive.  gamma None: no
+    LayerNorm, h = bf16(x + dropout(a)); beta, mean, rstd, x_new may then be None."""
     bf = torch.bfloat16
     _check(load().g2048_add_ln_fwd(x_ptr, int(x_row_stride), _dev(a, bf, 256 * T, "a", optional=True),
-                                   _dev(gamma, f32, 256, "gamma"), _dev(beta, f32, 256, "beta"),
+                                   _dev(gamma, f32, 256, "gamma", optional=True), _dev(beta, f32, 256, "beta", optional=True),
                                    _dev(x_new, f32, 256 * T, "x_new", optional=True), _dev(h, bf, 256 * T, "h"),
-                                   _dev(mean, f32, T, "mean"), _dev(rstd, f32, T, "rstd"), T, float(eps), float(p_drop),
+                                   _dev(mean, f32, T, "mean", optional=True), _dev(rstd, f32, T, "rstd", optional=True), T,
+                                   float(eps), float(p_drop),
                                    int(seed), seed_state or None, _stream()), "g2048_add_ln_fwd")
 
 
 def add_ln_bwd(xn_ptr: int, x_row_stride: int, g_x, g_h, mean, rstd, gamma, dx, da, dparams, T: int,
                p_drop: float, seed: int, seed_state: int = 0, g_x_period: int = 1):
     """dparams f32 [3, 256]: dgamma, dbeta, column sums of da.  dparams None: first stage only -> the workspace, f32
-    [rows, 768] partial sums (for ``reduce_jobs``)."""
+    [rows, 768] partial sums (for ``reduce_jobs``).  gamma None: the forward had no LayerNorm (xn_ptr 0, mean/rstd None)."""
     bf = torch.bfloat16
     ws = torch.empty(load().g2048_add_ln_bwd_workspace_floats(T), dtype=f32, device=dx.device)
     _check(load().g2048_add_ln_bwd(xn_ptr, int(x_row_stride), _dev(g_x, f32, 256 * (T // g_x_period), "g_x", optional=True),
-                                   _dev(g_h, bf, 256 * T, "g_h"), _dev(mean, f32, T, "mean"), _dev(rstd, f32, T, "rstd"),
-                                   _dev(gamma, f32, 256, "gamma"), _dev(dx, f32, 256 * T, "dx"),
+                                   _dev(g_h, bf, 256 * T, "g_h"), _dev(mean, f32, T, "mean", optional=True),
+                                   _dev(rstd, f32, T, "rstd", optional=True), _dev(gamma, f32, 256, "gamma", optional=True),
+                                   _dev(dx, f32, 256 * T, "dx"),
                                    _dev(da, bf, 256 * T, "da", optional=True), _dev(dparams, f32, 768, "dparams", optional=True),
                                    ws.data_ptr(), T, float(p_drop), int(seed), seed_state or None, int(g_x_period), _stream()),
            "g2048_add_ln_bwd")

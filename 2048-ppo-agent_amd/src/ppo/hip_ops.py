@@ -737,6 +737,53 @@ class _LinearAddLayerNorm(torch.autograd.Function):
         return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None, None, None
 
 
+class _LinearAddCast(torch.autograd.Function):
+    """``bf16(x + dropout(Linear(u)))``: the closing Linear of the LAST sub-layer (linear2 of the last encoder layer, no
+    LayerNorm follows), whose output the heads read in bf16.  ``g2048_add_ln_fwd/bwd`` with gamma = NULL: one launch instead
+    of dropout + add + cast (+ a second cast for the critic head), and in the backward one launch instead of two casts, an
+    add, masked_scale and the bias gradient's column sum.  u bf16, wb/bb bf16 shadows of the f32 masters weight/bias, x f32
+    rows of 256; returns the bf16 tensor."""
+
+    @staticmethod
+    def forward(ctx, u, weight, bias, wb, bb, x, p_drop):
+        from ..g2048 import native as nv
+
+        with torch.autocast("cuda", enabled=False):
+            a = F.linear(u, wb, bb)
+        ctx.params = (weight, bias)
+        xr, row_stride = _residual_rows(x)
+        T = xr.numel() // 256
+        h = torch.empty(xr.shape, dtype=torch.bfloat16, device=x.device)
+        seed = _seed_pair(xr, p_drop)
+        nv.add_ln_fwd(xr.data_ptr(), row_stride, a, None, None, None, h, None, None, T, 0.0, p_drop, *seed)
+        ctx.save_for_backward(u, wb)
+        ctx.meta = (p_drop, seed, tuple(xr.shape))
+        return h
+
+    @staticmethod
+    def backward(ctx, g_h):
+        from ..g2048 import native as nv
+
+        u, wb = ctx.saved_tensors
+        p_drop, seed, shape = ctx.meta
+        T = g_h.numel() // 256
+        dx = torch.empty(shape, dtype=torch.float32, device=g_h.device)
+        da = torch.empty(shape, dtype=torch.bfloat16, device=g_h.device)
+        weight, bias = ctx.params
+        sink = _sink_for(weight, bias)
+        dparams = None if sink is not None else torch.empty((3, 256), dtype=torch.float32, device=g_h.device)
+        ws = nv.add_ln_bwd(0, 256, None, g_h.contiguous(), None, None, None, dx, da, dparams, T, p_drop, *seed)
+        with torch.autocast("cuda", enabled=False):
+            da2, u2 = da.view(T, 256), u.reshape(T, -1)
+            du = (da2 @ wb).view(u.shape) if ctx.needs_input_grad[0] else None
+            if sink is not None:
+                sink.add(bias, ws[:, 512:], 768, 256, ws.shape[0])
+                _sink_weight(sink, weight, da2, u2)
+                return du, None, None, None, None, dx, None
+            dw = _SideWork.run((da2, u2), lambda: _dweight(da2, u2))
+        return du, dw, dparams[2], None, None, dx, None
+
+
 class _LinearReluDropout(torch.autograd.Function):
     """``dropout(relu(Linear(h)))`` (linear1 of the feed-forward block).  At the update's shapes the whole thing is one
     GEMM with a fused epilogue (``g2048_linear_relu_dropout_bf16``), otherwise a GEMM plus ``g2048_relu_dropout_fwd``.  Only

@@ -208,7 +208,9 @@ int g2048_attn_bwd(const void *q, const void *k, const void *v, const void *dout
  * `x = x + dropout1(sa(norm1(x)))`, `x = x + dropout2(ff(norm2(x)))`).
  * x f32 rows of 256 with element stride x_row_stride (a strided view of the residual stream is fine); a bf16 [T][256]
  * or NULL (then x_new is not written and h = LayerNorm(x)); x_new f32 [T][256]; h bf16 [T][256]; mean, rstd f32 [T]
- * (saved for the backward).  seed, seed_state: as for g2048_attn_fwd; pass the same pair to the backward. */
+ * (saved for the backward).  seed, seed_state: as for g2048_attn_fwd; pass the same pair to the backward.
+ * gamma NULL: no LayerNorm, h = bf16(x + dropout(a)) (the output of the LAST sub-layer, which the heads read in bf16);
+ * beta, mean, rstd and x_new may then be NULL too. */
 int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void *a, const float *gamma, const float *beta,
                      float *x_new, void *h, float *mean, float *rstd, int64_t T, float eps, float p_drop,
                      uint64_t seed, const uint64_t *seed_state, void *stream);
@@ -218,7 +220,8 @@ int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void *a, const 
  * da bf16 [T][256] or NULL = dropout-masked dx (gradient for a); dparams f32 [3][256] = dgamma, dbeta and the column
  * sums of da (= the bias gradient of the Linear that produced a; zeros when da is NULL), summed in a fixed order;
  * workspace: g2048_add_ln_bwd_workspace_floats(T) floats of scratch.  dparams NULL: first stage only, the workspace then
- * holds f32 [workspace floats / 768][3 * 256] partial sums (dgamma | dbeta | bias gradient) for g2048_reduce_jobs. */
+ * holds f32 [workspace floats / 768][3 * 256] partial sums (dgamma | dbeta | bias gradient) for g2048_reduce_jobs.
+ * gamma NULL (the forward ran without LayerNorm): dx = g_x + g_h, dgamma = dbeta = 0; x_norm, mean, rstd are not read. */
 int64_t g2048_add_ln_bwd_workspace_floats(int64_t T);
 int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
                      const float *rstd, const float *gamma, float *dx, void *da, float *dparams, float *workspace,

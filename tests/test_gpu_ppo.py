@@ -888,3 +888,55 @@ def test_graphed_rollout_forward_of_the_mlp_policy(dev, tmp_path, monkeypatch):
     tr.update_policy(batch_size=256, n_epochs=1)
     tr.collect_rollouts(512, 1)
     assert len(tr._rollout_graphs) == 1 and n1 > 512 and tr.rollout_buffer.buffer_size > 512
+
+
+def test_linear_add_cast_node_matches_torch(dev):
+    """``_LinearAddCast`` (g2048_add_ln_fwd/bwd with gamma NULL): bf16(x + dropout(Linear(u))) and its gradients; p = 0
+    against autograd of the same expression, p > 0 against the mask the forward itself drew."""
+    from src.ppo.hip_ops import GradSink, _LinearAddCast, grad_sink
+
+    torch.manual_seed(13)
+    B, K = 2048, 1024
+    w = (torch.randn(256, K, device=dev) / K ** 0.5).requires_grad_()
+    b = (torch.randn(256, device=dev) * 0.1).requires_grad_()
+    wb, bb = w.detach().to(torch.bfloat16), b.detach().to(torch.bfloat16)
+    stream = torch.randn(B, 17, 256, device=dev)
+    x = stream[:, :1].detach().requires_grad_()  # [B, 1, 256] with row stride 17 * 256: read in place
+    assert not x.is_contiguous() or x.stride(0) == 256
+    u = torch.randn(B, 1, K, device=dev).to(torch.bfloat16).requires_grad_()
+    g = torch.randn(B, 1, 256, device=dev).to(torch.bfloat16)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        h = _LinearAddCast.apply(u, w, b, wb, bb, x, 0.0)
+    ur, xr, wr, br = (t.detach().clone().requires_grad_() for t in (u, x, wb, bb))
+    ref = (xr + torch.nn.functional.linear(ur, wr, br).float()).to(torch.bfloat16)
+    assert h.dtype == torch.bfloat16 and h.shape == (B, 1, 256) and torch.equal(h, ref)
+    h.backward(g)
+    ref.backward(g)
+    assert torch.equal(x.grad, xr.grad) and torch.allclose(u.grad.float(), ur.grad.float(), rtol=2e-2, atol=2e-2)
+    assert (w.grad - wr.grad.float()).norm() / wr.grad.float().norm() < 6e-3
+    assert (b.grad - br.grad.float()).norm() / br.grad.float().norm() < 6e-3
+    # dropout: the backward re-draws the forward's mask (a >= 3 everywhere, so kept / dropped can be read off the output);
+    # with a sink the weight / bias gradients land in the targets
+    w2 = (torch.randn(256, K, device=dev) * 0.01 / K ** 0.5).requires_grad_()
+    b2 = (4.0 + torch.randn(256, device=dev) * 0.1).requires_grad_()
+    wb2, bb2 = w2.detach().to(torch.bfloat16), b2.detach().to(torch.bfloat16)
+    tw, tb = torch.zeros_like(w2), torch.zeros_like(b2)
+    x2 = torch.zeros(B, 1, 256, device=dev, requires_grad=True)
+    u2 = u.detach().clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        h2 = _LinearAddCast.apply(u2, w2, b2, wb2, bb2, x2, 0.25)
+    a = torch.nn.functional.linear(u2.detach(), wb2, bb2).float()
+    assert a.min() > 3
+    kept = h2.float() != 0
+    assert abs(kept.float().mean().item() - 0.75) < 0.01
+    assert torch.allclose(h2.float()[kept], (a / 0.75)[kept], rtol=1e-2)
+    with grad_sink(GradSink({id(w2): tw, id(b2): tb})):
+        h2.backward(g)
+    assert w2.grad is None and b2.grad is None and torch.equal(x2.grad, g.float())
+    da = torch.where(kept, g.float() / 0.75, torch.zeros_like(a)).to(torch.bfloat16)
+    du_ref = (da.view(B, 256) @ wb2).view(B, 1, K)
+    assert torch.allclose(u2.grad.float(), du_ref.float(), rtol=2e-2, atol=2e-3)
+    db_ref = da.float().sum((0, 1))
+    assert (tb - db_ref).norm() / db_ref.norm() < 1e-3
+    dw_ref = da.view(B, 256).float().t() @ u2.detach().view(B, K).float()
+    assert (tw - dw_ref).norm() / dw_ref.norm() < 6e-3
