@@ -187,4 +187,7 @@ class TransformerEncoder(nn.Module):
                                cls_link_in=cls_link if i == last else None)
         if self.encoder.norm is not None:
             x = self.encoder.norm(x)
-        return x[:, 0, :] if reduction == "cls" else x[:, 1:, :].mean(dim=1)
+        if reduction == "cls":
+            # a CLS-only last layer leaves [B, 1, D]: a view (its backward is free) instead of a select (zero-fill + copy)
+            return x.reshape(x.shape[0], x.shape[2]) if x.shape[1] == 1 else x[:, 0, :]
+        return x[:, 1:, :].mean(dim=1)
