@@ -1,3 +1,5 @@
+"""Parameter-update norm, loss scale and gradient norm per optimiser step across GradScaler growth events (growth every 6
+steps): g2048_opt_step in the captured update, PyTorch's unscale/clip/AdamW in the captured update, g2048_opt_step eager."""
 import os, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "2048-ppo-agent_amd")); sys.path.insert(0, ROOT)
