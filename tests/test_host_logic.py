@@ -224,3 +224,27 @@ def test_default_shape_agent_and_loss_match_reference():
         loss, pl, vl, el, nlp = tr._compute_ppo_loss(boards, actions, masks, t("old_logp"), t("adv"), t("ret"))
     for got, key in ((loss, "loss_total"), (pl, "loss_policy"), (vl, "loss_value"), (el, "loss_entropy"), (nlp, "new_logp")):
         np.testing.assert_allclose(got.numpy(), REF[f"default/{key}"], atol=1e-5, rtol=1e-5)
+
+
+def test_mlp_agent_host_paths_and_graph_gating():
+    """Without a HIP device the MLP policy runs the generic forward (the one-hot GEMM written as a gather-sum), the bf16
+    rollout path and the captured forward stay off, and the engine keeps its live-board compaction."""
+    from src.ppo import MLPAgent, TorchActionFunction
+
+    torch.manual_seed(3)
+    agent = MLPAgent()
+    boards = torch.randint(0, 12, (9, 16), dtype=torch.uint8)
+    assert not agent._rollout_bf16_ok(boards)
+    with torch.no_grad():
+        logits, values = agent(boards)
+        oh = torch.nn.functional.one_hot(boards.long(), 31).float().flatten(1)
+        h = torch.relu(agent.trunk_hidden(torch.relu(agent.trunk_in(oh))))
+        assert torch.allclose(logits, agent.actor(h), atol=1e-5) and torch.allclose(values, agent.critic(h), atol=1e-5)
+        masked, _ = agent(boards, torch.tensor([[1, 0, 1, 1]] * 9))
+    assert (masked[:, 1] < -1e7).all() and torch.allclose(masked[:, [0, 2, 3]], logits[:, [0, 2, 3]])
+    fn = TorchActionFunction(agent, graph_cache={})
+    assert fn.compact is True and fn._graph_cache is None  # CPU: no capture, compaction stays
+    lg, vl = fn.policy_fn(boards, None)
+    assert torch.allclose(lg, logits, atol=1e-5) and vl.shape == (9,)
+    agent.prepare_rollout()  # no-op off the device
+    assert agent._trunk_shadow is None and agent._head_shadow is None
