@@ -454,7 +454,7 @@ namespace {
 constexpr int EMB_D = 256, EMB_CLASSES = 32, EMB_SEQ = 17, EMB_BLOCKS = 256;
 
 __global__ void __launch_bounds__(256)
-k_embed_fwd(const uint8_t *__restrict__ boards, const float *__restrict__ wt, const float *__restrict__ pe,
+k_embed_fwd(const uint8_t *__restrict__ boards, const float *__restrict__ wt, int w_ld, const float *__restrict__ pe,
             const float *__restrict__ cls, float *__restrict__ x0, int64_t n_rows, float inv_keep, uint32_t thr, uint32_t s0,
             uint32_t s1, const uint64_t *seed_state) {
     mix_seed_state(seed_state, s0, s1);
@@ -467,7 +467,13 @@ k_embed_fwd(const uint8_t *__restrict__ boards, const float *__restrict__ wt, co
             v = reinterpret_cast<const float4 *>(cls)[lane];
         } else {
             const int e = min((int)boards[m * 16 + c - 1], 30);  // wt has 31 rows; the env never exceeds 17
-            const float4 a = reinterpret_cast<const float4 *>(wt + (size_t)e * EMB_D)[lane];
+            float4 a;
+            if (w_ld == 0) {  // class-major table [31][256]
+                a = reinterpret_cast<const float4 *>(wt + (size_t)e * EMB_D)[lane];
+            } else {  // the nn.Linear weight itself, [256][w_ld]: four strided reads of a 31 KB table that stays in cache
+                const float *w = wt + (size_t)(4 * lane) * w_ld + e;
+                a = make_float4(w[0], w[w_ld], w[2 * w_ld], w[3 * w_ld]);
+            }
             const float4 b = reinterpret_cast<const float4 *>(pe + (size_t)(c - 1) * EMB_D)[lane];
             v = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
             if (thr) {
@@ -538,15 +544,15 @@ k_embed_bwd(const uint8_t *__restrict__ boards, const float *__restrict__ dx0, f
 
 }  // namespace
 
-extern "C" int g2048_embed_fwd(const uint8_t *boards, const float *wt, const float *pe, const float *cls, float *x0, int64_t M,
+extern "C" int g2048_embed_fwd(const uint8_t *boards, const float *wt, int w_ld, const float *pe, const float *cls, float *x0, int64_t M,
                                float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream) {
-    if (!boards || !wt || !pe || !cls || !x0 || M <= 0 || !(p_drop >= 0.f && p_drop < 1.f) ||
-        (((uintptr_t)wt | (uintptr_t)pe | (uintptr_t)cls | (uintptr_t)x0) & 15))
+    if (!boards || !wt || !pe || !cls || !x0 || M <= 0 || !(p_drop >= 0.f && p_drop < 1.f) || (w_ld != 0 && w_ld < 31) ||
+        (((uintptr_t)pe | (uintptr_t)cls | (uintptr_t)x0) & 15) || ((uintptr_t)wt & (w_ld ? 3 : 15)))
         return G2048_EINVAL;
     const int64_t n_rows = M * EMB_SEQ;
     int64_t blocks = (n_rows + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_embed_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, boards, wt, pe, cls, x0, n_rows,
+    hipLaunchKernelGGL(k_embed_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, boards, wt, w_ld, pe, cls, x0, n_rows,
                        1.0f / (1.0f - p_drop), (uint32_t)(p_drop * 16777216.0f), (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
     return done();
 }
@@ -555,7 +561,7 @@ extern "C" int64_t g2048_embed_bwd_workspace_floats(int64_t M) { return M <= 0 ?
 
 extern "C" int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, float *workspace, int64_t M, float p_drop,
                                uint64_t seed, const uint64_t *seed_state, void *stream) {
-    if (!boards || !dx0 || !dwt_dcls || !workspace || M <= 0 || !(p_drop >= 0.f && p_drop < 1.f) ||
+    if (!boards || !dx0 || !workspace || M <= 0 || !(p_drop >= 0.f && p_drop < 1.f) ||
         (((uintptr_t)dx0 | (uintptr_t)dwt_dcls | (uintptr_t)workspace) & 15))
         return G2048_EINVAL;
     // per call, not latched: the attribute is per device, and a latch would be the library's only global state
@@ -565,7 +571,8 @@ extern "C" int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *d
     const int64_t n_rows = M * EMB_SEQ;
     hipLaunchKernelGGL(k_embed_bwd, dim3(EMB_BLOCKS), dim3(256), lds, (hipStream_t)stream, boards, dx0, workspace, n_rows,
                        1.0f / (1.0f - p_drop), (uint32_t)(p_drop * 16777216.0f), (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
-    hipLaunchKernelGGL(k_colsum_final, dim3(EMB_CLASSES * EMB_D / CF_COLS), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream, workspace,
-                       EMB_BLOCKS, EMB_CLASSES * EMB_D, dwt_dcls);
+    if (dwt_dcls)
+        hipLaunchKernelGGL(k_colsum_final, dim3(EMB_CLASSES * EMB_D / CF_COLS), dim3(CF_COLS * CF_SLICES), 0, (hipStream_t)stream,
+                           workspace, EMB_BLOCKS, EMB_CLASSES * EMB_D, dwt_dcls);
     return done();
 }

@@ -34,7 +34,7 @@ __device__ __forceinline__ float bf2f(uint32_t hi16) { return __uint_as_float(hi
 constexpr int RJ_WIDE8_COLS = RJ_THREADS * 8;  // 2048 columns per workgroup
 // the all-vector case of the wide shape (host and device must agree: it decides the number of workgroups of the job)
 __host__ __device__ inline bool wide8(const g2048_reduce_job &J) {
-    return J.src_bf16 && J.parts <= RJ_WIDE_MAX_PARTS && J.n % 8 == 0 && J.part_stride % 8 == 0 && !((uintptr_t)J.src & 15) &&
+    return !J.transpose_rows && J.src_bf16 && J.parts <= RJ_WIDE_MAX_PARTS && J.n % 8 == 0 && J.part_stride % 8 == 0 && !((uintptr_t)J.src & 15) &&
            !((uintptr_t)J.dst & 15);
 }
 
@@ -66,7 +66,7 @@ k_reduce_jobs(JobTable T) {
         dst[1] = make_float4(a[4], a[5], a[6], a[7]);
         return;
     }
-    const bool wide = J.parts <= RJ_WIDE_MAX_PARTS;
+    const bool wide = J.parts <= RJ_WIDE_MAX_PARTS && !J.transpose_rows;
     const int tx = wide ? (int)threadIdx.x : (int)threadIdx.x % RJ_TX, ty = wide ? 0 : (int)threadIdx.x / RJ_TX;
     const int p_step = wide ? 1 : RJ_TY;
     const int c0 = ((int)blockIdx.x - T.first_block[j]) * (wide ? RJ_WIDE_COLS : RJ_COLS) + tx * RJ_VEC;
@@ -127,8 +127,13 @@ k_reduce_jobs(JobTable T) {
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < RJ_TY; ++k)
             for (int q = 0; q < 4; ++q) s[q] += red[k][tx * RJ_VEC + q];
-        for (int q = 0; q < 4; ++q)
-            if (c0 + q < J.n) J.dst[c0 + q] = s[q];
+        // transpose_rows = R: the n columns are a row-major [R][n / R] matrix whose sum is stored transposed ([n / R][R]): the
+        // embedding gradient is accumulated per class ([31][256]) and belongs to an nn.Linear weight ([256][31])
+        const int R = J.transpose_rows, cols = R ? J.n / R : 0;
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + q;
+            if (c < J.n) J.dst[R ? (int64_t)(c % cols) * R + c / cols : c] = s[q];
+        }
     }
 }
 
@@ -138,7 +143,8 @@ extern "C" int g2048_reduce_jobs(const g2048_reduce_job *jobs, int n_jobs, void 
     if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return G2048_EINVAL;
     if (n_jobs == 0) return 0;
     for (int i = 0; i < n_jobs; ++i)
-        if (!jobs[i].src || !jobs[i].dst || jobs[i].n <= 0 || jobs[i].parts <= 0 || (jobs[i].parts > 1 && jobs[i].part_stride < jobs[i].n) ||
+        if (!jobs[i].src || !jobs[i].dst || jobs[i].n <= 0 || jobs[i].parts <= 0 || jobs[i].transpose_rows < 0 ||
+            (jobs[i].transpose_rows && jobs[i].n % jobs[i].transpose_rows) || (jobs[i].parts > 1 && jobs[i].part_stride < jobs[i].n) ||
             ((uintptr_t)jobs[i].src & (jobs[i].src_bf16 ? 1 : 3)) || ((uintptr_t)jobs[i].dst & 3))
             return G2048_EINVAL;
     for (int base = 0; base < n_jobs; base += RJ_MAX) {
@@ -148,7 +154,8 @@ extern "C" int g2048_reduce_jobs(const g2048_reduce_job *jobs, int n_jobs, void 
         for (int i = 0; i < T.n_jobs; ++i) {
             T.job[i] = jobs[base + i];
             T.first_block[i] = blocks;
-            const int cols = wide8(jobs[base + i]) ? RJ_WIDE8_COLS : jobs[base + i].parts <= RJ_WIDE_MAX_PARTS ? RJ_WIDE_COLS : RJ_COLS;
+            const int cols = wide8(jobs[base + i]) ? RJ_WIDE8_COLS
+                             : (jobs[base + i].parts <= RJ_WIDE_MAX_PARTS && !jobs[base + i].transpose_rows) ? RJ_WIDE_COLS : RJ_COLS;
             blocks += (jobs[base + i].n + cols - 1) / cols;
         }
         for (int i = T.n_jobs; i <= RJ_MAX; ++i) T.first_block[i] = blocks;

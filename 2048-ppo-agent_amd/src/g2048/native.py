@@ -59,7 +59,7 @@ SIGNATURES = {
     "g2048_linear_relu_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, C.c_uint64, _vp, _vp, _vp],
     "g2048_linear_mask_bwd_workspace_floats": [_i64, _i32],
     "g2048_linear_mask_bwd_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp],
-    "g2048_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_embed_fwd": [_vp, _vp, C.c_int, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_embed_bwd_workspace_floats": [_i64],
     "g2048_embed_bwd": [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_gather_minibatch": [_vp, _i64, _i64] + [_vp] * 13,
@@ -420,20 +420,23 @@ def colsum_partial(x: torch.Tensor) -> torch.Tensor:
 
 class ReduceJob(C.Structure):  # g2048_reduce_job
     _fields_ = [("src", _vp), ("dst", _vp), ("part_stride", _i64), ("n", C.c_int32), ("parts", C.c_int32),
-                ("src_bf16", C.c_int32), ("reserved", C.c_int32)]
+                ("src_bf16", C.c_int32), ("transpose_rows", C.c_int32)]
 
 
 def reduce_jobs(jobs):
-    """jobs: list of (src tensor whose first element is part 0 / column 0, dst f32 tensor, part_stride, n, parts):
-    dst[c] = sum_p src[p * part_stride + c]; all of them in one launch (per 64)."""
+    """jobs: list of (src tensor whose first element is part 0 / column 0, dst f32 tensor, part_stride, n, parts[,
+    transpose_rows]): dst[c] = sum_p src[p * part_stride + c] (transpose_rows R: the [R][n / R] sum stored as [n / R][R]); all
+    of them in one launch (per 64)."""
     if not jobs:
         return
     recs = []
-    for src, dst, stride, n, parts in jobs:
+    for job in jobs:
+        src, dst, stride, n, parts = job[:5]
+        tr = int(job[5]) if len(job) > 5 else 0
         if not src.is_cuda or src.dtype not in (torch.bfloat16, f32) or not dst.is_cuda or dst.dtype != f32 \
                 or not dst.is_contiguous() or dst.numel() < n:
             raise NativeError(f"reduce_jobs: bad job {src.dtype} {tuple(src.shape)} -> {dst.dtype} {tuple(dst.shape)} (n={n})")
-        recs.append(ReduceJob(src.data_ptr(), dst.data_ptr(), int(stride), int(n), int(parts), int(src.dtype == torch.bfloat16), 0))
+        recs.append(ReduceJob(src.data_ptr(), dst.data_ptr(), int(stride), int(n), int(parts), int(src.dtype == torch.bfloat16), tr))
     arr = (ReduceJob * len(recs))(*recs)
     _check(load().g2048_reduce_jobs(C.cast(arr, _vp), len(recs), _stream()), "g2048_reduce_jobs")
 
@@ -523,18 +526,25 @@ def linear_mask_bwd(dy2: torch.Tensor, weight_t: torch.Tensor, mask: torch.Tenso
 
 
 def embed_fwd(boards, wt, pe, cls, x0, p_drop: float = 0.0, seed: int = 0, seed_state: int = 0):
+    """wt: the class-major table f32 [31, 256], or the nn.Linear weight f32 [256, 31] itself (read in place)."""
     M = boards.numel() // 16
-    _check(load().g2048_embed_fwd(_dev(boards, u8, 16 * M, "boards"), _dev(wt, f32, 31 * 256, "wt"), _dev(pe, f32, 16 * 256, "pe"),
+    w_ld = 0 if tuple(wt.shape) == (31, 256) else int(wt.shape[1])
+    if w_ld and (wt.dim() != 2 or wt.shape[0] != 256 or w_ld < 31):
+        raise NativeError(f"embed_fwd: weight must be [31, 256] or [256, >= 31], got {tuple(wt.shape)}")
+    _check(load().g2048_embed_fwd(_dev(boards, u8, 16 * M, "boards"), _dev(wt, f32, 31 * 256, "wt"), w_ld,
+                                  _dev(pe, f32, 16 * 256, "pe"),
                                   _dev(cls, f32, 256, "cls"), _dev(x0, f32, M * 17 * 256, "x0"), M, float(p_drop), int(seed),
                                   seed_state or None, _stream()), "g2048_embed_fwd")
 
 
 def embed_bwd(boards, dx0, dwt_dcls, p_drop: float = 0.0, seed: int = 0, seed_state: int = 0):
+    """dwt_dcls None: first stage only -> the workspace, f32 [rows, 32 * 256] partial sums (for ``reduce_jobs``)."""
     M = boards.numel() // 16
     ws = torch.empty(load().g2048_embed_bwd_workspace_floats(M), dtype=f32, device=dx0.device)
     _check(load().g2048_embed_bwd(_dev(boards, u8, 16 * M, "boards"), _dev(dx0, f32, M * 17 * 256, "dx0"),
-                                  _dev(dwt_dcls, f32, 32 * 256, "dwt_dcls"), ws.data_ptr(), M, float(p_drop), int(seed),
-                                  seed_state or None, _stream()), "g2048_embed_bwd")
+                                  _dev(dwt_dcls, f32, 32 * 256, "dwt_dcls", optional=True), ws.data_ptr(), M, float(p_drop),
+                                  int(seed), seed_state or None, _stream()), "g2048_embed_bwd")
+    return ws.view(-1, 32 * 256) if dwt_dcls is None else None
 
 
 OPT_CHUNK = 2048  # G2048_OPT_CHUNK

@@ -151,11 +151,12 @@ class GradSink:
     def takes(self, *params) -> bool:
         return all(p is not None and id(p) in self.targets for p in params)
 
-    def add(self, param, src: torch.Tensor, part_stride: int, n: int, parts: int, dst_offset: int = 0):
+    def add(self, param, src: torch.Tensor, part_stride: int, n: int, parts: int, dst_offset: int = 0, transpose_rows: int = 0):
         """grad(param).flatten()[dst_offset : dst_offset + n] = sum over parts of src (src's first element = part 0,
-        column 0; the tensor is kept alive until ``flush``)."""
+        column 0; the tensor is kept alive until ``flush``); ``transpose_rows`` R: the summed [R][n / R] matrix is stored
+        transposed."""
         dst = self.targets[id(param)].view(-1)[dst_offset:dst_offset + n]
-        self.jobs.append((src, dst, part_stride, n, parts))
+        self.jobs.append((src, dst, part_stride, n, parts, transpose_rows))
         self.written.add(id(param))
 
     def flush(self):
@@ -874,12 +875,15 @@ class _EmbedBoards(torch.autograd.Function):
 
         boards = boards.contiguous()
         M = boards.shape[0]
-        wt = emb_weight.detach().float().t().contiguous()
+        w = emb_weight.detach()
+        # the f32 nn.Linear weight [256, 31] is read in place (no transposed copy per minibatch)
+        wt = w if (w.dtype == torch.float32 and w.is_contiguous()) else w.float().t().contiguous()
         x0 = torch.empty((M, 17, 256), dtype=torch.float32, device=boards.device)
         seed = _seed_pair(x0, p_drop)
         nv.embed_fwd(boards, wt, pe, cls.detach().float().reshape(256).contiguous(), x0, p_drop, *seed)
         ctx.save_for_backward(boards)
         ctx.meta = (p_drop, seed, emb_weight.dtype, cls.dtype)
+        ctx.params = (emb_weight, cls)
         return x0
 
     @staticmethod
@@ -888,6 +892,13 @@ class _EmbedBoards(torch.autograd.Function):
 
         (boards,) = ctx.saved_tensors
         p_drop, seed, w_dtype, c_dtype = ctx.meta
+        emb_weight, cls = ctx.params
+        sink = _sink_for(emb_weight, cls) if (w_dtype == torch.float32 and c_dtype == torch.float32) else None
+        if sink is not None:  # per-workgroup [32][256] images: 31 class rows -> the [256, 31] weight gradient, row 31 -> cls
+            ws = nv.embed_bwd(boards, g.contiguous(), None, p_drop, *seed)
+            sink.add(emb_weight, ws, ws.shape[1], 31 * 256, ws.shape[0], transpose_rows=31)
+            sink.add(cls, ws[:, 31 * 256:], ws.shape[1], 256, ws.shape[0])
+            return None, None, None, None, None
         out = torch.empty((32, 256), dtype=torch.float32, device=g.device)
         nv.embed_bwd(boards, g.contiguous(), out, p_drop, *seed)
         return None, out[:31].t().to(w_dtype), None, out[31].view(1, 1, 256).to(c_dtype), None

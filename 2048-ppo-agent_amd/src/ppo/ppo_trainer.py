@@ -541,12 +541,12 @@ class PPOTrainer:
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self._group)
             n_per_epoch = int(t.item())
         self.agent.train()
-        sums = torch.zeros(4, dtype=torch.float64, device=self.device)  # policy, value, entropy, total
+        acc5 = torch.zeros(5, dtype=torch.float64, device=self.device)  # sums over all minibatches: policy, value, entropy, total, kl
+        kl_before = 0.0
         n_updates = 0
         mean_kl = 0.0
         packed = self._fused_loss_ok() and batches.packed()
         for epoch in range(n_epochs):
-            kl_sum = torch.zeros(1, dtype=torch.float64, device=self.device)
             done_batches = 0
             for idx in batches.indices():
                 if done_batches >= n_per_epoch:
@@ -591,20 +591,26 @@ class PPOTrainer:
                     # that caches derived weights keys on them (Bf16Shadow, the fused rollout encoder's packed weights)
                     torch.autograd.graph.increment_version(list(self.agent.parameters()))
                 self.lr_scheduler.step()
-                sums += stats
-                kl_sum += kl
+                if kl._base is not None and kl._base is stats._base and kl._base.numel() == 5:
+                    acc5 += kl._base  # the fused loss returns views of one [5] tensor: one accumulate launch, not two
+                else:
+                    acc5[:4] += stats
+                    acc5[4:] += kl
                 n_updates += 1
                 done_batches += 1
                 self.total_update_steps += 1
             self.total_epochs += 1
+            kl_now = acc5[4:5].clone()  # this rank's running sum; the epoch's share is the difference to the last epoch's
             if self.world > 1:
-                dist.all_reduce(kl_sum, group=self._group)
-                kl_sum /= self.world
-            mean_kl = float(kl_sum.item()) / done_batches if done_batches else 0.0
+                dist.all_reduce(kl_now, group=self._group)
+                kl_now /= self.world
+            kl_now = float(kl_now.item())
+            mean_kl = (kl_now - kl_before) / done_batches if done_batches else 0.0
+            kl_before = kl_now
             if mean_kl > self.target_kl:
                 logger.info("Early stopping at epoch %d due to high KL divergence: %.6f", epoch, mean_kl)
                 break
-        s = (sums / max(n_updates, 1)).tolist()
+        s = (acc5[:4] / max(n_updates, 1)).tolist()
         metrics = {"policy_loss": s[0] if n_updates else 0, "value_loss": s[1] if n_updates else 0,
                    "entropy_loss": s[2] if n_updates else 0, "total_loss": s[3] if n_updates else 0,
                    "kl_divergence": mean_kl, "n_updates": n_updates}

@@ -308,15 +308,18 @@ int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const void *weight_
 
 /* ---- policy network (update): token embedding of packed boards ---------------------------------------------- */
 
-/* x0[m][0] = cls, x0[m][1 + c] = dropout(wt[boards[m][c]] + pe[c]): the bias-free input Linear over the one-hot cell (wt =
- * input_embedding.weight^T, f32 [31][256]), the 2-D positional code (pe f32 [16][256]) and the CLS concat
+/* x0[m][0] = cls, x0[m][1 + c] = dropout(wt[boards[m][c]] + pe[c]): the bias-free input Linear over the one-hot cell (w_ld
+ * = 0: wt = input_embedding.weight^T, f32 [31][256], 16-byte aligned; w_ld >= 31: wt = the nn.Linear weight itself, f32
+ * [256][w_ld], read in place), the 2-D positional code (pe f32 [16][256]) and the CLS concat
  * (reference: src/ppo/ppo_agent.py:59-66,103-106; src/ppo/transformer_encoder.py:150-190).  boards u8 [M][16] with
  * cells <= 30, x0 f32 [M][17][256].  The positional encoding's dropout (p_drop; seed, seed_state as for g2048_attn_fwd)
  * applies to the 16 board tokens, not to the CLS row. */
-int g2048_embed_fwd(const uint8_t *boards, const float *wt, const float *pe, const float *cls, float *x0, int64_t M,
+int g2048_embed_fwd(const uint8_t *boards, const float *wt, int w_ld, const float *pe, const float *cls, float *x0, int64_t M,
                     float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
 /* dwt_dcls f32 [32][256]: rows 0..30 = gradient of wt (sum of dx0 rows by cell value), row 31 = gradient of cls; fixed
- * summation order.  dx0 f32 [M][17][256]; workspace: g2048_embed_bwd_workspace_floats(M) floats. */
+ * summation order.  dx0 f32 [M][17][256]; workspace: g2048_embed_bwd_workspace_floats(M) floats.  dwt_dcls NULL: first
+ * stage only, the workspace then holds f32 [workspace floats / 8192][32 * 256] partial sums for g2048_reduce_jobs (whose
+ * transpose_rows = 31 stores the first 31 * 256 columns as the [256][31] gradient of the nn.Linear weight). */
 int64_t g2048_embed_bwd_workspace_floats(int64_t M);
 int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, float *workspace, int64_t M, float p_drop,
                     uint64_t seed, const uint64_t *seed_state, void *stream);
@@ -332,10 +335,13 @@ int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, fl
  * g2048_linear_mask_bwd_bf16, g2048_embed_bwd, g2048_colsum: f32 [rows][N], rows = workspace floats / N), a bf16 -> f32
  * conversion (parts 1).  Replaces what PyTorch runs as one at::sum / copy kernel per parameter
  * (reference: loss.backward() at src/ppo/ppo_trainer.py:410-414).  jobs: host array, read during the call; src 2- (bf16) or
- * 4-byte aligned device memory, vector loads when 8-/16-byte aligned with part_stride % 4 == 0. */
+ * 4-byte aligned device memory, vector loads when 8-/16-byte aligned with part_stride % 4 == 0.
+ * transpose_rows = R > 0 (n a multiple of R): the n columns are a row-major [R][n / R] matrix and the sum is stored
+ * transposed, dst[(c % (n / R)) * R + c / (n / R)] - the embedding gradient is accumulated per class ([31][256]) and belongs
+ * to an nn.Linear weight ([256][31]); 0: dst[c]. */
 #define G2048_REDUCE_MAX_JOBS 64
 typedef struct {
-    const void *src; float *dst; int64_t part_stride; int32_t n, parts, src_bf16, reserved;
+    const void *src; float *dst; int64_t part_stride; int32_t n, parts, src_bf16, transpose_rows;
 } g2048_reduce_job;
 int g2048_reduce_jobs(const g2048_reduce_job *jobs, int n_jobs, void *stream);
 

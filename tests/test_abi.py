@@ -77,7 +77,8 @@ def test_invalid_arguments_return_einval_without_touching_a_device():
     assert lib.g2048_relu_dropout_bwd_workspace_floats(65, 1024) == 9 * 1024 and lib.g2048_relu_dropout_bwd_workspace_floats(34816, 1024) == 544 * 1024
     assert lib.g2048_linear_bf16(a, 256, a, 256, None, a, 256, 8, 200, 256, None) == -1       # K not a multiple of 128
     assert lib.g2048_linear_bf16(a, 128, a, 256, None, a, 256, 8, 256, 256, None) == -1       # ldx < K
-    assert lib.g2048_embed_fwd(None, a, a, a, a, 4, 0.0, 0, None, None) == -1
+    assert lib.g2048_embed_fwd(None, a, 0, a, a, a, 4, 0.0, 0, None, None) == -1
+    assert lib.g2048_embed_fwd(a, a, 30, a, a, a, 4, 0.0, 0, None, None) == -1  # an nn.Linear weight has >= 31 columns
     assert lib.g2048_embed_bwd(a, a, a, None, 4, 0.0, 0, None, None) == -1
     assert lib.g2048_embed_bwd_workspace_floats(4) == 256 * 32 * 256
     assert lib.g2048_ppo_loss(a, 0, a, 0, a, None, a, a, a, 0, 0.2, 0.5, 0.01, a, a, a, a, None, None) == -1   # M = 0

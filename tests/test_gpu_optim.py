@@ -260,8 +260,15 @@ def test_reduce_jobs_kernel(dev):
             jobs.append((wide[:, 256 * c:], dst, 768, 256, 100))
             want.append(wide[:, 256 * c:256 * (c + 1)].double().sum(0))
             outs.append(dst)
+    # transposed stores (transpose_rows): few parts and many parts, f32 and bf16 sources, a column block of a wider matrix
+    for parts, R, cols, dt, stride in ((256, 31, 256, torch.float32, 32 * 256), (3, 4, 8, torch.bfloat16, 32), (40, 5, 7, torch.float32, 35)):
+        src = torch.randn(parts, stride, device=dev).to(dt)
+        dst = torch.full((R * cols,), float("nan"), device=dev)
+        jobs.append((src, dst, stride, R * cols, parts, R))
+        want.append(src[:, :R * cols].double().sum(0).view(R, cols).t().reshape(-1))
+        outs.append(dst)
     nv.reduce_jobs(jobs)
-    for (src, dst, stride, n, parts), w, o in zip(jobs, want, outs):
+    for (src, dst, stride, n, parts, *_), w, o in zip(jobs, want, outs):
         tol = 1e-6 * float(src.float().abs().sum(0).max()) + 1e-7
         assert torch.allclose(o.double(), w, rtol=1e-6, atol=tol), (parts, n, src.dtype, (o.double() - w).abs().max().item())
     first = [o.clone() for o in outs]

@@ -780,6 +780,16 @@ def test_embed_boards_matches_torch(dev):
         again.backward(g)
         assert torch.equal(w.grad, got[0]) and torch.equal(cls.grad, got[1])
         w.grad = cls.grad = None
+        # with a GradSink both gradients come out of g2048_reduce_jobs (the weight's stored transposed, [256][31])
+        from src.ppo.hip_ops import GradSink, grad_sink
+
+        tw, tc = torch.full_like(w, float("nan")), torch.full_like(cls, float("nan"))
+        sunk = _EmbedBoards.apply(boards, w, pe, cls, 0.0)
+        with grad_sink(GradSink({id(w): tw, id(cls): tc})):
+            sunk.backward(g)
+        assert w.grad is None and cls.grad is None
+        assert torch.allclose(tw, got[0], rtol=1e-5, atol=1e-4 * max(1.0, M ** 0.5))
+        assert torch.allclose(tc, got[1], rtol=1e-5, atol=1e-4 * max(1.0, M ** 0.5))
     boards = torch.randint(0, 31, (4096, 16), device=dev, dtype=torch.uint8)
     w = torch.randn(256, 31, device=dev, requires_grad=True)
     pe = torch.zeros(16, 256, device=dev)
