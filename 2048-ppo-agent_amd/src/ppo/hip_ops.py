@@ -439,7 +439,8 @@ class _InProjCls(torch.autograd.Function):
         B, S, D = h.shape
         dq2, dkv2 = dq.reshape(B, D).contiguous(), dkv.reshape(B * S, 2 * D).contiguous()
         dh = (dkv2 @ wb[D:]).view(B, S, D)
-        dh[:, 0] += dq2 @ wb[:D]
+        dh0 = dh[:, 0]  # [B, D] with row stride S * D: the CLS rows receive the query's gradient in the GEMM's epilogue
+        torch.addmm(dh0, dq2, wb[:D], out=dh0)
         weight, bias = ctx.params
         sink = _sink_for(weight, bias)
         if sink is not None:  # the four pieces land in their slices of the in_proj gradients

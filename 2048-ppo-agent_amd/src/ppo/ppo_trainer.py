@@ -90,6 +90,7 @@ class _FusedPPOLoss(torch.autograd.Function):
         ctx.save_for_backward(dlogits, dvalues)
         ctx.prescaled = grad_scale is not None
         ctx.mark_non_differentiable(new_lp)
+        ctx.set_materialize_grads(False)  # no zero-filled [M] gradient for new_lp (one fill launch per minibatch)
         return sums, new_lp
 
     @staticmethod
