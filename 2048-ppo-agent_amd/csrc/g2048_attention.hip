@@ -38,6 +38,8 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     return *reinterpret_cast<const uint16_t *>(&b);
 }
 
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
 // 32 bf16 (64 B) -> 32 f32
 __device__ __forceinline__ void load_row(const uint16_t *p, float out[HD]) {
     const uint4 *p4 = reinterpret_cast<const uint4 *>(p);
@@ -289,6 +291,114 @@ __global__ void __launch_bounds__(64) k_attn_bwd1(Params P, const uint16_t *__re
     store_row(dq + b * P.q_sb + h * HD, acc);
 }
 
+// ------------------------------------------------------------------------------------------------ Sq = 1, row-coalesced
+// k_attn_fwd1 / k_attn_bwd1 give a lane a whole (sample, head) pair: 2048 x 8 pairs are 256 wavefronts, one per CU, each walking
+// 17 + 17 dependent 64-byte rows (19 / 31 us for 36 MB of K/V: 1.9 TB/s).  For H = 8 the eight heads of a token are one 512-byte
+// run of the packed K/V projection: here a 32-lane group owns a SAMPLE, lane (h, c) the 16-byte chunk c of head h, so every
+// K_j / V_j fetch of a group is one contiguous 512-byte row and there are 4x the wavefronts.  A head's score is a 4-lane sum
+// (2 shuffles), the softmax over the 17 keys and both sums over keys (O, dQ) are in-lane, dK_j / dV_j are stored as the same
+// 512-byte rows.  (First attempt, one lane per KEY with a transposing 31-shuffle reduction: rows of 17 different tokens per load
+// instruction - 55 / 63 us, three times slower than the scalar kernels.)  Dropout uses the scalar kernels' element index.
+__device__ __forceinline__ void unpack8(const uint4 u, float f[8]) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    for (int e = 0; e < 4; ++e) {
+        f[2 * e] = __uint_as_float(w[e] << 16);
+        f[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float f[8]) {
+    return make_uint4(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7]));
+}
+__device__ __forceinline__ float quad_dot(const float a[8], const uint4 u) {
+    float f[8], s = 0.f;
+    unpack8(u, f);
+    for (int d = 0; d < 8; ++d) s = fmaf(a[d], f[d], s);
+    s += __shfl_xor(s, 1);
+    return s + __shfl_xor(s, 2);
+}
+
+__global__ void __launch_bounds__(256) k_attn_fwd1_rows(Params P, uint16_t *__restrict__ o, float *__restrict__ lse) {
+    mix_seed_state(P);
+    const int l = threadIdx.x & 31, h = l >> 2, c = l & 3;
+    const int64_t b = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (b >= P.B) return;  // (a whole 32-lane group)
+    const int64_t pair = b * 8 + h;
+    const int col = h * HD + 8 * c;
+    float q[8], s[SK], acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unpack8(*reinterpret_cast<const uint4 *>(P.q + b * P.q_sb + col), q);
+    uint4 kk[SK], vv[SK];
+#pragma unroll
+    for (int j = 0; j < SK; ++j) kk[j] = *reinterpret_cast<const uint4 *>(P.k + b * P.k_sb + j * P.k_ss + col);
+#pragma unroll
+    for (int j = 0; j < SK; ++j) vv[j] = *reinterpret_cast<const uint4 *>(P.v + b * P.v_sb + j * P.v_ss + col);
+    float m = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < SK; ++j) {
+        s[j] = quad_dot(q, kk[j]) * P.scale;
+        m = fmaxf(m, s[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < SK; ++j) {
+        s[j] = __expf(s[j] - m);
+        sum += s[j];
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < SK; ++j) {
+        const float pj = (P.p_drop > 0.f && !keep_mask(P, (uint64_t)pair * 32 + j)) ? 0.f : s[j] * inv * P.inv_keep;
+        float v[8];
+        unpack8(vv[j], v);
+        for (int d = 0; d < 8; ++d) acc[d] = fmaf(pj, v[d], acc[d]);
+    }
+    *reinterpret_cast<uint4 *>(o + b * (8 * HD) + col) = pack8(acc);
+    if (c == 0) lse[pair] = m + __logf(sum);
+}
+
+__global__ void __launch_bounds__(256) k_attn_bwd1_rows(Params P, const uint16_t *__restrict__ dout, const float *__restrict__ lse,
+                                                        uint16_t *__restrict__ dq, uint16_t *__restrict__ dk,
+                                                        uint16_t *__restrict__ dv) {
+    mix_seed_state(P);
+    const int l = threadIdx.x & 31, h = l >> 2, c = l & 3;
+    const int64_t b = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (b >= P.B) return;
+    const int64_t pair = b * 8 + h;
+    const int col = h * HD + 8 * c;
+    float q[8], g[8], p[SK], dp[SK], acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unpack8(*reinterpret_cast<const uint4 *>(P.q + b * P.q_sb + col), q);
+    unpack8(*reinterpret_cast<const uint4 *>(dout + b * (8 * HD) + col), g);
+    uint4 kk[SK], vv[SK];
+#pragma unroll
+    for (int j = 0; j < SK; ++j) kk[j] = *reinterpret_cast<const uint4 *>(P.k + b * P.k_sb + j * P.k_ss + col);
+#pragma unroll
+    for (int j = 0; j < SK; ++j) vv[j] = *reinterpret_cast<const uint4 *>(P.v + b * P.v_sb + j * P.v_ss + col);
+    const float L = lse[pair];
+    float delta = 0.f;
+#pragma unroll
+    for (int j = 0; j < SK; ++j) {
+        p[j] = __expf(quad_dot(q, kk[j]) * P.scale - L);
+        const bool keep = !(P.p_drop > 0.f) || keep_mask(P, (uint64_t)pair * 32 + j);
+        dp[j] = keep ? quad_dot(g, vv[j]) * P.inv_keep : 0.f;
+        delta = fmaf(p[j], dp[j], delta);
+        const float pt = keep ? p[j] * P.inv_keep : 0.f;  // dV_j = Ptilde_j * dO
+        float t[8];
+        for (int d = 0; d < 8; ++d) t[d] = pt * g[d];
+        *reinterpret_cast<uint4 *>(dv + b * P.v_sb + j * P.v_ss + col) = pack8(t);
+    }
+#pragma unroll
+    for (int j = 0; j < SK; ++j) {
+        const float ds = p[j] * (dp[j] - delta) * P.scale;  // dK_j = ds_j * q,  dQ = sum_j ds_j * K_j
+        float t[8], kf[8];
+        unpack8(kk[j], kf);
+        for (int d = 0; d < 8; ++d) {
+            acc[d] = fmaf(ds, kf[d], acc[d]);
+            t[d] = ds * q[d];
+        }
+        *reinterpret_cast<uint4 *>(dk + b * P.k_sb + j * P.k_ss + col) = pack8(t);
+    }
+    *reinterpret_cast<uint4 *>(dq + b * P.q_sb + col) = pack8(acc);
+}
+
 // ------------------------------------------------------------------------------------------------ Sq = 17 on MFMA
 // The 17 x 17 problems of one (sample, head) pair mapped onto v_mfma_f32_32x32x16_bf16 tiles (17 of 32 rows and columns
 // used: the matrix cores are idle either way, the point is to take the ~2700 f32 FMAs per lane off the vector ALU and the
@@ -312,7 +422,6 @@ __device__ __forceinline__ int key_of(int i, int hf) { return (i & 3) + 8 * (i >
 // vmcnt(0) + s_barrier of __syncthreads(), which would also drain the global prefetch of the next head
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ float xhalf(float x) { return __shfl_xor(x, 32); }
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
 
 __global__ void __launch_bounds__(64) k_attn_fwd17_mfma(Params P, uint16_t *__restrict__ o, float *__restrict__ lse) {
     mix_seed_state(P);
@@ -545,7 +654,8 @@ inline int done() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }
-// G2048_ATTN_SCALAR=1 keeps the scalar 17-token kernels (read per call: no latch, no library state)
+// G2048_ATTN_SCALAR=1 keeps the scalar kernels (17-token: one lane per query row; CLS row: one lane per pair) (read per call: no
+// latch, no library state)
 inline bool use_mfma17() {
     const char *e = getenv("G2048_ATTN_SCALAR");
     return !(e && e[0] == '1');
@@ -566,6 +676,8 @@ extern "C" int g2048_attn_fwd(const void *q, const void *k, const void *v, void 
     else if (Sq == SK)
         hipLaunchKernelGGL(k_attn_fwd17, dim3((unsigned)((pairs + PAIRS - 1) / PAIRS)), dim3(64), 0, (hipStream_t)stream, P,
                            (uint16_t *)o, lse);
+    else if (H == 8 && use_mfma17())
+        hipLaunchKernelGGL(k_attn_fwd1_rows, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, (hipStream_t)stream, P, (uint16_t *)o, lse);
     else
         hipLaunchKernelGGL(k_attn_fwd1, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, (hipStream_t)stream, P,
                            (uint16_t *)o, lse);
@@ -586,6 +698,9 @@ extern "C" int g2048_attn_bwd(const void *q, const void *k, const void *v, const
                            (const uint16_t *)dout, lse, (uint16_t *)dq, (uint16_t *)dk, (uint16_t *)dv);
     else if (Sq == SK)
         hipLaunchKernelGGL(k_attn_bwd17, dim3((unsigned)((pairs + PAIRS - 1) / PAIRS)), dim3(64), 0, (hipStream_t)stream, P,
+                           (const uint16_t *)dout, lse, (uint16_t *)dq, (uint16_t *)dk, (uint16_t *)dv);
+    else if (H == 8 && use_mfma17())
+        hipLaunchKernelGGL(k_attn_bwd1_rows, dim3((unsigned)((B + 7) / 8)), dim3(256), 0, (hipStream_t)stream, P,
                            (const uint16_t *)dout, lse, (uint16_t *)dq, (uint16_t *)dk, (uint16_t *)dv);
     else
         hipLaunchKernelGGL(k_attn_bwd1, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, (hipStream_t)stream, P,

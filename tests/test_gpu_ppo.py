@@ -302,6 +302,41 @@ def test_mfma_attention_equals_scalar_attention(dev, monkeypatch):
                 assert torch.equal((o1 == 0).all(-1), (o2 == 0).all(-1))
 
 
+def test_cls_attention_row_coalesced_equals_scalar(dev, monkeypatch):
+    """The CLS-row attention (Sq = 1) with a 32-lane group per sample and 512-byte K/V row fetches (default for 8 heads) vs
+    one lane per (sample, head) pair (G2048_ATTN_SCALAR=1), same inputs and dropout seed, K/V read from the packed
+    [B, 17, 2 * 256] projection: f32 arithmetic in both, only the summation order differs; ragged B (the last workgroup's
+    groups exit early)."""
+    from src.g2048 import native as nv
+
+    H, hd, S = 8, 32, 17
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+    torch.manual_seed(4)
+    for B in (1, 3, 301, 2048):
+        for p_drop in (0.0, 0.1):
+            hw = H * hd
+            q = (torch.randn(B, 1, hw, device=dev) * 1.5).to(torch.bfloat16)
+            kv = (torch.randn(B, S, 2 * hw, device=dev) * 1.5).to(torch.bfloat16)
+            do = torch.randn(B, 1, hw, device=dev).to(torch.bfloat16)
+            strides = (hw, 0, S * 2 * hw, 2 * hw, S * 2 * hw, 2 * hw)
+            res = {}
+            for impl in ("rows", "scalar"):
+                monkeypatch.setenv("G2048_ATTN_SCALAR", "1" if impl == "scalar" else "0")
+                o = torch.empty((B, 1, hw), dtype=torch.bfloat16, device=dev)
+                lse = torch.empty((B, H, 1), dtype=torch.float32, device=dev)
+                nv.attn_fwd(q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 2 * hw, o, lse, B, H, 1, strides, hd ** -0.5, p_drop, 77, 0)
+                dq, dkv = torch.empty_like(q), torch.full_like(kv, float("nan"))
+                nv.attn_bwd(q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 2 * hw, do, lse, dq.data_ptr(), dkv.data_ptr(),
+                            dkv.data_ptr() + 2 * hw, B, H, 1, strides, hd ** -0.5, p_drop, 77, 0)
+                res[impl] = (o, lse, dq, dkv)
+            (o1, l1, q1, k1), (o2, l2, q2, k2) = res["rows"], res["scalar"]
+            assert torch.isfinite(k1.float()).all()  # every K / V gradient row was written
+            assert rel(o1, o2) < 4e-3 and torch.allclose(l1, l2, rtol=1e-5, atol=1e-4), (B, p_drop)
+            assert rel(q1, q2) < 4e-3 and rel(k1, k2) < 4e-3, (B, p_drop, rel(q1, q2), rel(k1, k2))
+            if p_drop > 0:
+                assert torch.equal(k1[..., hw:] == 0, k2[..., hw:] == 0)  # dV rows of dropped keys are zero in both
+
+
 def test_fused_add_layernorm_matches_torch(dev):
     """g2048_add_ln_fwd/bwd vs torch (`x + dropout(a)` then F.layer_norm in f32, cast to bf16): values and all five
     gradients, contiguous and strided ([B, 1, 256] slice) residual input, ragged row counts; with dropout the kept
