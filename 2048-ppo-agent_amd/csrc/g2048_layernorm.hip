@@ -17,7 +17,10 @@
 
 namespace {
 
-constexpr int D = 256, ROWS_PER_BLOCK = 64, WAVES = 4;
+constexpr int D = 256, WAVES = 4;
+// rows per workgroup of the add+LN backward: 64 for the 34 816-token activations; 8 for the 2048-row ones of the CLS-only layer
+// (32 workgroups whose waves walk 16 rows each, two dependent wave reductions per row, took 12-16 us for 2 MB)
+__host__ __device__ inline int ln_rows_per_block(int64_t T) { return T >= 16384 ? 64 : 8; }
 
 __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -115,6 +118,7 @@ k_add_ln_bwd(const float *__restrict__ xn, int64_t xn_rs, const float *__restric
     const bool norm = gamma != nullptr;  // NULL: the forward had no LayerNorm (h = bf16(x_new)): dx = g_x + g_h
     const float4 g = norm ? reinterpret_cast<const float4 *>(gamma)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0}, dsum[4] = {0, 0, 0, 0};
+    const int ROWS_PER_BLOCK = ln_rows_per_block(T);
     const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
     // the loads of the next row are issued before this row's reductions (two dependent wave reductions per row would
     // otherwise leave one row's 40 bytes per lane in flight)
@@ -313,7 +317,7 @@ extern "C" int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int6
 }
 
 extern "C" int64_t g2048_add_ln_bwd_workspace_floats(int64_t T) {
-    return T <= 0 ? 0 : ((T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * 3 * D;
+    return T <= 0 ? 0 : ((T + ln_rows_per_block(T) - 1) / ln_rows_per_block(T)) * 3 * D;
 }
 
 extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x, const void *g_h, const float *mean,
@@ -325,7 +329,7 @@ extern "C" int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const
         (((uintptr_t)g_h | (uintptr_t)da) & 7))
         return G2048_EINVAL;
     const uint32_t thr = da ? (uint32_t)(p_drop * 16777216.0f) : 0u;
-    const int64_t blocks = (T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    const int64_t blocks = (T + ln_rows_per_block(T) - 1) / ln_rows_per_block(T);
     hipLaunchKernelGGL(k_add_ln_bwd, dim3((unsigned)blocks), dim3(64 * WAVES), 0, (hipStream_t)stream, x_norm, x_row_stride, g_x,
                        (const uint16_t *)g_h, mean, rstd, gamma, dx, (uint16_t *)da, workspace, T, 1.0f / (1.0f - p_drop), thr,
                        (uint32_t)seed, (uint32_t)(seed >> 32), seed_state, g_x_period);
