@@ -30,6 +30,14 @@ class Bf16Shadow:
         self.maintainer = None
         Bf16Shadow._live.add(self)
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle of an agent: the copy starts cold - no buffers and no maintainer (both belong to the
+        original's optimiser, which must not travel with a pickled module) - and registers itself like a new shadow."""
+        return {"params": self.params, "transposed": self.transposed}
+
+    def __setstate__(self, state):
+        self.__init__(state["params"], state["transposed"])
+
     def invalidate(self):
         self.key = None
 

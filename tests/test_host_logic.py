@@ -248,3 +248,33 @@ def test_mlp_agent_host_paths_and_graph_gating():
     assert torch.allclose(lg, logits, atol=1e-5) and vl.shape == (9,)
     agent.prepare_rollout()  # no-op off the device
     assert agent._trunk_shadow is None and agent._head_shadow is None
+
+
+class _ShadowOwner(torch.nn.Module):  # (module level: pickle needs an importable class)
+    def __init__(self):
+        super().__init__()
+        from src.ppo.hip_ops import Bf16Shadow
+
+        self.lin = torch.nn.Linear(8, 8)
+        self.sh = Bf16Shadow([self.lin.weight, self.lin.bias], transposed=(0,))
+
+
+def test_bf16_shadow_copies_start_cold():
+    """copy.deepcopy / pickle of a module that owns a Bf16Shadow: the copy shadows the COPIED parameters, is registered for
+    invalidation, and carries neither the original's buffers nor its maintainer (an optimiser must not travel with a pickled
+    agent)."""
+    import copy
+    import pickle
+
+    from src.ppo.hip_ops import Bf16Shadow
+
+    m = _ShadowOwner()
+    views = m.sh()
+    assert views[0].dtype == torch.bfloat16 and m.sh.tviews[0].shape == (8, 8)
+    m.sh.maintainer = object()  # what FlatAdamWStep.adopt_shadows sets
+    for c in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert c.sh is not m.sh and c.sh.maintainer is None and c.sh.views is None and c.sh.key is None
+        assert c.sh.params[0] is c.lin.weight and c.sh.transposed == (0,) and c.sh in Bf16Shadow._live
+        with torch.no_grad():
+            c.lin.weight.add_(1.0)
+        assert torch.equal(c.sh()[0], c.lin.weight.detach().to(torch.bfloat16)) and not c.sh.maintained()
