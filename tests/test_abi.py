@@ -67,6 +67,10 @@ def test_invalid_arguments_return_einval_without_touching_a_device():
     assert lib.g2048_linear_relu_dropout_bf16(a, 256, a, 256, None, a, 1024, 4, 256, 1024, 0.0, 0, None, None, None) == -1  # no bias
     assert lib.g2048_linear_mask_bwd_bf16(a, 256, a, 256, None, a, 1024, a, a, 4, 256, 1024, 0.0, None) == -1  # no mask
     assert lib.g2048_reduce_jobs(None, 3, None) == -1 and lib.g2048_reduce_jobs(None, 0, None) == 0
+    # a transposed store needs n to be a multiple of its row count; negative row counts are rejected (checked before any launch)
+    for n, rows in ((10, 3), (12, -1)):
+        job = (nv.ReduceJob * 1)(nv.ReduceJob(a, a, 16, n, 2, 0, rows))
+        assert lib.g2048_reduce_jobs(C.cast(job, C.c_void_p), 1, None) == -1
     assert lib.g2048_opt_step(None, 0, a, a, a, None, 0, 0.5, None, 0, None, None, 2.0, 0.5, 2000, None, None, None) == -1
     assert lib.g2048_opt_workspace_floats(10) >= 12
     assert lib.g2048_add_ln_bwd_workspace_floats(65) == 9 * 3 * 256 and lib.g2048_add_ln_bwd_workspace_floats(34816) == 544 * 3 * 256
