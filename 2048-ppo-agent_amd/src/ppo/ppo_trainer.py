@@ -11,7 +11,6 @@ test are reduced globally so every rank takes the same decisions.
 from __future__ import annotations
 
 import contextlib
-import gc
 import logging
 import os
 from collections import deque
@@ -29,6 +28,7 @@ from ..runs.batch_runner import BatchRunner
 from .data_loader import DeviceBatches, PPODataset
 from .rollout_buffer import RolloutBuffer
 from .torch_action_wrapper import TorchActionFunction
+from .capture import capture as capture_graph
 from .hip_ops import Bf16Shadow, GradSink, grad_sink, graph_seed_state, weight_grads_on_side_stream
 
 logger = logging.getLogger(__name__)
@@ -129,25 +129,13 @@ class _GraphedFwdBwd:
             trainer._flat_step.adopt_shadows(list(Bf16Shadow._live))
         Bf16Shadow.invalidate_all()  # (for the others) the bf16 weight refresh must be part of the graph
         seed_word = graph_seed_state(dev)  # allocated outside the capture
-        # thread_local: only this thread's calls are checked during the capture.  Other threads (the RCCL watchdog of a
-        # multi-GPU run polling its events) must not be able to invalidate it; the autograd worker's launches are
-        # captured either way because capture is a property of the stream
-        # No garbage collection while the stream is capturing: a collection that frees device tensors of earlier work (another
-        # trainer's graph pool, tensors last used on a side stream) makes the caching allocator issue event calls that are
-        # illegal during capture, and the process aborts (seen once in a test run, inside g2048_reduce_jobs' ctypes call, with
-        # "Garbage-collecting" on the stack).  Collect before, not during.
-        gc.collect()
-        gc_was_enabled = gc.isenabled()
-        gc.disable()
-        try:
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                seed_word.add_(1)  # new dropout masks on every replay (the HIP kernels read it at run time)
-                self.out = self._fwd_bwd()
-                if trainer._flat_grad is not None:
-                    trainer._collect_grads(point_grads=False)  # graph-owned gradients -> all-reduce bucket, one copy
-        finally:
-            if gc_was_enabled:
-                gc.enable()
+        # capture.capture(): thread-local error mode, and no cyclic garbage collection while the stream is capturing (a
+        # collection that finalises an earlier trainer's CUDAGraph / graph pool on this thread aborts the process: capture.py)
+        with capture_graph(self.graph):
+            seed_word.add_(1)  # new dropout masks on every replay (the HIP kernels read it at run time)
+            self.out = self._fwd_bwd()
+            if trainer._flat_grad is not None:
+                trainer._collect_grads(point_grads=False)  # graph-owned gradients -> all-reduce bucket, one copy
         Bf16Shadow.invalidate_all()  # nothing was copied during the capture itself
         # the gradients the replay writes (graph pool) / the tensors the optimizer reads after a replay
         self.grads = [p.grad for p in trainer.agent.parameters()]
@@ -283,6 +271,11 @@ class PPOTrainer:
         self.last_save_timestep = 0
         self.load_checkpoint_path = None
         self.last_rollout_stats: Dict[str, float] = {}
+
+    @property
+    def rollout_graph_fallback(self):
+        """repr of the exception that made the captured rollout forward (TorchActionFunction._graphed) drop to eager mode."""
+        return self._rollout_graphs.get("fallback")
 
     # ------------------------------------------------------------------ multi-GPU plumbing
     def _bind_flat_grads(self):
@@ -620,6 +613,11 @@ class PPOTrainer:
         # how the minibatches ran: replayed hipGraph (and how many captured layouts) or the eager fallback
         metrics["hip_graph"] = bool(self.use_hip_graph and self._graphs)
         metrics["hip_graphs_captured"] = len(self._graphs)
+        if self.hip_graph_fallback:
+            metrics["hip_graph_fallback"] = self.hip_graph_fallback
+        # the rollout forward's own capture (agents with ``rollout_graph_ok``): why it runs eagerly, if it does
+        if self.rollout_graph_fallback:
+            metrics["rollout_graph_fallback"] = self.rollout_graph_fallback
         if self.lr_scheduler is not None:
             self.writer.add_scalar("train/lr", self.lr_scheduler.get_last_lr()[0], self.total_timesteps)
         self.writer.add_scalar("train/total_epochs", self.total_epochs, self.total_timesteps)

@@ -15,6 +15,7 @@ import torch
 from ..actions import _common as C
 from ..env_definitions import BOARD_FLAT_DIM, OBS_DIM
 from ..g2048 import native as nv
+from .capture import capture as capture_graph
 
 
 class TorchActionFunction:
@@ -98,7 +99,7 @@ class TorchActionFunction:
                         self._forward(static_in, boards.device)
                 torch.cuda.current_stream(boards.device).wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                with capture_graph(graph):  # thread-local error mode + no garbage collection while capturing (capture.py)
                     out = self._forward(static_in, boards.device)
                 entry = (graph, static_in, out)
             except Exception as e:  # not capturable: eager from now on (the reason stays visible in the cache)

@@ -390,6 +390,8 @@ def main():
     }
     if trainer.hip_graph_fallback:
         out["hip_graph_fallback"] = trainer.hip_graph_fallback
+    if trainer.rollout_graph_fallback:
+        out["rollout_graph_fallback"] = trainer.rollout_graph_fallback
     if args.workload == "transformer65536":
         # the update as a whole: forward + backward of the policy over one minibatch = 3 x the forward FLOPs the "cls"
         # reduction needs (same accounting as policy_encoder), against the time a minibatch takes end to end
@@ -475,6 +477,8 @@ def main():
                 n, s, m = run_iterations(ml, 4096, 1, 3)
                 out["mlp4096"] = {"value": round(n / s, 1), "unit": "env-steps/sec", "boards": 4096,
                                   "hip_graph": bool(m.get("hip_graph", False)),
+                                  "rollout_graph": ml.rollout_graph_fallback is None and len(ml._rollout_graphs) > 0,
+                                  **({"rollout_graph_fallback": ml.rollout_graph_fallback} if ml.rollout_graph_fallback else {}),
                                   "what": "BASELINE.json configs[1]: 4 096 boards, MLP policy (flattened one-hot -> 512 -> 512 "
                                           "trunk + the reference's heads), full PPO iterations, reference trainer config"}
                 del ml

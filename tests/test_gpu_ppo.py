@@ -985,3 +985,32 @@ def test_linear_add_cast_node_matches_torch(dev):
     assert (tb - db_ref).norm() / db_ref.norm() < 1e-3
     dw_ref = da.view(B, 256).float().t() @ u2.detach().view(B, K).float()
     assert (tw - dw_ref).norm() / dw_ref.norm() < 6e-3
+
+
+def test_no_garbage_collection_while_a_stream_is_capturing(dev, tmp_path, monkeypatch):
+    """Both capture sites (the update's _GraphedFwdBwd and the MLP policy's rollout forward) run under capture.capture():
+    with the collector's thresholds far below their defaults not one collection starts while the stream is capturing, although
+    earlier trainers with captured graphs are garbage at that moment (the situation of the recorded abort)."""
+    import gc
+
+    from src.ppo.capture import CollectionsWhileCapturing
+
+    monkeypatch.chdir(tmp_path)
+
+    def make(agent):
+        return PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), OPTIM, max_steps=100, device=dev,
+                          rollout_amp=True, use_action_mask=True, max_samples_per_epoch=2048, log_dir=str(tmp_path / "lg"))
+
+    old = gc.get_threshold()
+    try:
+        with CollectionsWhileCapturing() as seen:
+            for _ in range(2):  # the second round's captures start with the first round's trainers as cyclic garbage
+                gc.set_threshold(100, 5, 5)  # (default 700, 10, 10: a capture allocates thousands of objects)
+                tr = make(MLPAgent())
+                tr.collect_rollouts(256, 1)  # captures the rollout forward
+                m = tr.update_policy(batch_size=256, n_epochs=1)  # captures the update
+                assert m["hip_graph"] and "rollout_graph_fallback" not in m and len(tr._rollout_graphs) == 1
+                del tr
+        assert seen.total > 0 and seen.during_capture == 0
+    finally:
+        gc.set_threshold(*old)

@@ -278,3 +278,38 @@ def test_bf16_shadow_copies_start_cold():
         with torch.no_grad():
             c.lin.weight.add_(1.0)
         assert torch.equal(c.sh()[0], c.lin.weight.detach().to(torch.bfloat16)) and not c.sh.maintained()
+
+
+def test_capture_guard_keeps_the_collector_off_and_restores_it():
+    """capture.no_gc_during_capture: collect first, cyclic collector off inside, previous state restored (also on error);
+    CollectionsWhileCapturing sees collections (none of them 'while capturing' on a CPU box)."""
+    import gc
+
+    from src.ppo.capture import CollectionsWhileCapturing, no_gc_during_capture
+
+    class Node:
+        def __init__(self):
+            self.me = self
+
+    assert gc.isenabled()
+    with CollectionsWhileCapturing() as seen:
+        with no_gc_during_capture():
+            assert not gc.isenabled()
+            before = seen.total  # (the guard's own gc.collect() has been counted)
+            assert before >= 1
+            junk = [Node() for _ in range(20000)]  # far beyond the generation-0 threshold: would trigger a collection
+            del junk
+            assert seen.total == before
+        assert gc.isenabled()
+        with pytest.raises(RuntimeError):
+            with no_gc_during_capture():
+                raise RuntimeError("x")
+        assert gc.isenabled()
+        gc.disable()
+        try:
+            with no_gc_during_capture():
+                pass
+            assert not gc.isenabled()  # it was off before: stays off
+        finally:
+            gc.enable()
+    assert seen.during_capture == 0
