@@ -84,62 +84,6 @@ class Bf16Shadow:
         return self.views
 
 
-class _SideWork:
-    """Weight and bias gradients on a second HIP stream.
-
-    In the backward of a Linear only the input gradient is on the critical path; dW (a split-K GEMM plus its reduction)
-    and db (column sums) feed nothing but the optimiser.  Inside ``weight_grads_on_side_stream()`` the autograd nodes of this
-    module enqueue that work on a side stream that forks from the backward stream at the point of the call and is joined
-    when the context exits; captured in a hipGraph this becomes a parallel branch, so the many small launches of the
-    weight-gradient path fill the gaps of the (bandwidth-bound) activation-gradient chain instead of extending it.
-    Operands are kept alive until the join (the caching allocator knows nothing of the side stream's reads)."""
-
-    enabled = False
-    max_rows = 0  # 0: every weight gradient; N: only those whose reduction runs over at most N rows (the CLS-only layer and the
-    #               heads: 2048 rows per minibatch, every kernel launch-latency-bound, so a parallel branch does shorten the chain)
-    streams, pending, used = {}, {}, set()
-
-    @classmethod
-    def run(cls, keep, fn):
-        if not cls.enabled or (cls.max_rows and keep[0].shape[0] > cls.max_rows):
-            return fn()
-        dev = keep[0].device
-        side = cls.streams.get(dev)
-        if side is None:
-            side = cls.streams[dev] = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            out = fn()
-        cls.pending.setdefault(dev, []).extend(keep)
-        cls.used.add(dev)
-        return out
-
-    @classmethod
-    def join(cls):
-        for dev in list(cls.used):
-            torch.cuda.current_stream(dev).wait_stream(cls.streams[dev])
-        cls.used.clear()
-        cls.pending.clear()
-
-
-class weight_grads_on_side_stream:
-    """Context manager around ``loss.backward()``: see ``_SideWork``.  Gradients of weights and biases are complete (on
-    the current stream) when the context exits."""
-
-    def __init__(self, enabled: bool = True, max_rows: int = 0):
-        self.on, self.max_rows = enabled, int(max_rows)
-
-    def __enter__(self):
-        self.prev = (_SideWork.enabled, _SideWork.max_rows)
-        _SideWork.enabled, _SideWork.max_rows = bool(self.on), self.max_rows
-        return self
-
-    def __exit__(self, *exc):
-        _SideWork.enabled, _SideWork.max_rows = self.prev
-        _SideWork.join()
-        return False
-
-
 class GradSink:
     """All second-stage gradient reductions of one backward pass in ONE launch (``g2048_reduce_jobs``).
 
@@ -149,7 +93,13 @@ class GradSink:
     them (the 16 split-K slices of a weight gradient, the per-workgroup column sums of a bias gradient), register a job
     and return None for that input; ``flush()`` then sums every job straight into its target.  That replaces ~50
     launches per minibatch (at::sum per weight, k_colsum_final per bias, bf16 -> f32 copies) by one.
-    ``written`` holds the ids of the parameters whose gradient the sink produced (autograd never saw them)."""
+    ``written`` holds the ids of the parameters whose gradient the sink produced (autograd never saw them).
+
+    Concurrency: ``GradSink.active`` (like ``Bf16Shadow._live`` and the capture-site counter of ``_seed_pair``) is
+    PROCESS-GLOBAL state, on purpose: the backward nodes that read it run on autograd's device worker thread, not on the thread
+    that entered ``grad_sink``, so a thread-local would be invisible to them.  The consequence is the engine's model of one
+    process per GPU with ONE update in flight: two threads running backward passes of this module at the same time would
+    share (and corrupt) the job list.  ``grad_sink.__enter__`` refuses to nest over a different sink for that reason."""
 
     active = None
 
@@ -181,6 +131,8 @@ class grad_sink:
         self.sink = sink
 
     def __enter__(self):
+        if GradSink.active is not None and self.sink is not None and GradSink.active is not self.sink:
+            raise RuntimeError("a GradSink is already active in this process: one update in flight per process (see GradSink)")
         self.prev, GradSink.active = GradSink.active, self.sink
         return self.sink
 
@@ -273,14 +225,10 @@ class FFNLink:
         self.bias_param, self.db_sunk = None, False  # linear1's bias; True when a GradSink took its gradient
 
 
-import os as _os
 
-# the wide projections of the update (in_proj 256 -> 768, the last layer's K/V 256 -> 512) through g2048_linear_bf16 instead of
-# hipBLASLt: 2.73 -> 2.69 ms per minibatch in the pipeline (isolated and cache-warm hipBLASLt is the faster one,
-# tools/probe_linear.py).  G2048_HIP_LINEAR_WIDE=0 switches back.
-_HIP_LINEAR_WIDE = _os.environ.get("G2048_HIP_LINEAR_WIDE", "1") != "0"
-_HEAD_RELU_FUSED = _os.environ.get("G2048_HEAD_RELU_FUSED", "1") != "0"  # Linear+ReLU of the heads as one node (_LinearRelu)
-_SINK_SLICES = int(_os.environ.get("G2048_SINK_SLICES", "16"))  # split-K slices of a weight gradient when a GradSink sums them
+# the wide projections of the update (in_proj 256 -> 768, the last layer's K/V 256 -> 512) go through g2048_linear_bf16 instead of
+# hipBLASLt: 2.73 -> 2.69 ms per minibatch in the pipeline (isolated and cache-warm hipBLASLt is the faster one, tools/probe_linear.py)
+_SINK_SLICES = 16  # split-K slices of a weight gradient when a GradSink sums them
 
 
 def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
@@ -295,7 +243,7 @@ def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
 
 
 def _sink_weight(sink, param, dy2, x2, dst_offset: int = 0):
-    parts = _SideWork.run((dy2, x2), lambda: _dweight_parts(dy2, x2))
+    parts = _dweight_parts(dy2, x2)
     n = parts.shape[1] * parts.shape[2]
     sink.add(param, parts, n, n, parts.shape[0], dst_offset)
 
@@ -312,10 +260,10 @@ def _sink_bias(sink, param, dy2, dst_offset: int = 0):
 
     N = dy2.shape[-1]
     if _colsum_sinkable(dy2):
-        ws = _SideWork.run((dy2,), lambda: nv.colsum_partial(dy2))
+        ws = nv.colsum_partial(dy2)
         sink.add(param, ws, N, N, ws.shape[0], dst_offset)
     else:  # widths the partial kernel does not take: a finished column sum, copied into place by the sink
-        sink.add(param, _SideWork.run((dy2,), lambda: _colsum(dy2).contiguous()), N, N, 1, dst_offset)
+        sink.add(param, _colsum(dy2).contiguous(), N, N, 1, dst_offset)
 
 
 def _dweight(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
@@ -345,7 +293,7 @@ class _LinearSplitK(torch.autograd.Function):
             if bias is not None and bb is None:
                 bb = bias.to(torch.bfloat16)
             y = None
-            if _HIP_LINEAR_WIDE and bias is not None and bias.dtype == torch.float32:
+            if bias is not None and bias.dtype == torch.float32:
                 y = _hip_linear(xb.reshape(-1, xb.shape[-1]), wb, bias.detach())
                 if y is not None:
                     y = y.view(*xb.shape[:-1], wb.shape[0])
@@ -371,8 +319,8 @@ class _LinearSplitK(torch.autograd.Function):
                 if bias is not None:
                     _sink_bias(sink, bias, dy2)
                 return dx, None, None, None, None
-            dw, db = _SideWork.run((dy2, x2), lambda: (_dweight(dy2, x2).to(w_dtype),
-                                                       None if b_dtype is None else _colsum(dy2).to(b_dtype)))
+            dw = _dweight(dy2, x2).to(w_dtype)
+            db = None if b_dtype is None else _colsum(dy2).to(b_dtype)
         return dx, dw, db, None, None
 
 
@@ -414,7 +362,7 @@ class _LinearRelu(torch.autograd.Function):
                 sink.add(bias, ws, ws.shape[1], ws.shape[1], ws.shape[0])
                 _sink_weight(sink, weight, dz, x2)
                 return dx, None, None, None, None
-            dw = _SideWork.run((dz, x2), lambda: _dweight(dz, x2))
+            dw = _dweight(dz, x2)
         return dx, dw, db, None, None
 
 
@@ -431,7 +379,7 @@ class _InProjCls(torch.autograd.Function):
         h_cls = h[:, 0].contiguous()
         q = F.linear(h_cls, wb[:D], bb[:D]).view(B, 1, D)
         kv = None
-        if _HIP_LINEAR_WIDE and bias.dtype == torch.float32:
+        if bias.dtype == torch.float32:
             kv = _hip_linear(h.reshape(B * S, D), wb[D:], bias.detach()[D:])
             if kv is not None:
                 kv = kv.view(B, S, 2 * D)
@@ -467,7 +415,7 @@ class _InProjCls(torch.autograd.Function):
             _colsum(dkv2, db[D:])
             return dw, db
 
-        dw, db = _SideWork.run((dq2, dkv2, h, h_cls), weight_grads)
+        dw, db = weight_grads()
         return dh, dw, db, None, None
 
 
@@ -743,7 +691,7 @@ class _LinearAddLayerNorm(torch.autograd.Function):
             if sink is not None:
                 _sink_weight(sink, weight, da2, u2)
                 return du, None, None, None, None, dx, None, None, None, None, None, None, None
-            dw = _SideWork.run((da2, u2), lambda: _dweight(da2, u2))
+            dw = _dweight(da2, u2)
         return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None, None, None
 
 
@@ -790,7 +738,7 @@ class _LinearAddCast(torch.autograd.Function):
                 sink.add(bias, ws[:, 512:], 768, 256, ws.shape[0])
                 _sink_weight(sink, weight, da2, u2)
                 return du, None, None, None, None, dx, None
-            dw = _SideWork.run((da2, u2), lambda: _dweight(da2, u2))
+            dw = _dweight(da2, u2)
         return du, dw, dparams[2], None, None, dx, None
 
 
@@ -851,7 +799,7 @@ class _LinearReluDropout(torch.autograd.Function):
                 if not db_done:  # the link delivered a finished bias gradient: let the sink copy it into place
                     sink.add(bias, db.contiguous(), db.numel(), db.numel(), 1)
                 return dh, None, None, None, None, None, None
-            dw = _SideWork.run((dz2, h2), lambda: _dweight(dz2, h2))
+            dw = _dweight(dz2, h2)
         return dh, dw, (None if db_done else db), None, None, None, None
 
 
@@ -927,7 +875,7 @@ def _train_bf16(t: torch.Tensor, weight: torch.Tensor) -> bool:
 def _linear(x: torch.Tensor, weight: torch.Tensor, bias, wb=None, bb=None, relu: bool = False) -> torch.Tensor:
     """``F.linear`` (``relu``: followed by ReLU), through the update path's autograd nodes under bf16 autocast with gradients."""
     if _train_bf16(x, weight):
-        if relu and _HEAD_RELU_FUSED and _LinearRelu.ok(x, weight, bias, wb, bb):
+        if relu and _LinearRelu.ok(x, weight, bias, wb, bb):
             return _LinearRelu.apply(x, weight, bias, wb, bb)
         y = _LinearSplitK.apply(x, weight, bias, wb, bb)
     else:

@@ -28,8 +28,9 @@ from ..runs.batch_runner import BatchRunner
 from .data_loader import DeviceBatches, PPODataset
 from .rollout_buffer import RolloutBuffer
 from .torch_action_wrapper import TorchActionFunction
+from . import torch_compat
 from .capture import capture as capture_graph
-from .hip_ops import Bf16Shadow, GradSink, grad_sink, graph_seed_state, weight_grads_on_side_stream
+from .hip_ops import Bf16Shadow, GradSink, grad_sink, graph_seed_state
 
 logger = logging.getLogger(__name__)
 
@@ -188,6 +189,8 @@ class PPOTrainer:
 
         self.mixed_precision = mixed_precision
         self.use_amp = mixed_precision is not None and self.device.type == "cuda"
+        if self.device.type == "cuda":
+            torch_compat.check()  # the private torch interfaces of the device path: one clear error instead of a late one
         if self.use_amp:
             self.scaler = GradScaler()
             self.amp_dtype = torch.float16 if mixed_precision == "float16" else torch.bfloat16
@@ -246,14 +249,6 @@ class PPOTrainer:
             use_hip_graph = (self.use_amp and self.amp_dtype == torch.bfloat16
                              and getattr(self.agent, "hip_graph_safe", False))
         self.use_hip_graph = bool(use_hip_graph) and self.device.type == "cuda"
-        # weight/bias gradients of the update's Linears on a second stream (a parallel branch of the captured graph).
-        # Off by default: measured at minibatch 2048 the kernels do overlap (GPU-busy 3.18 -> 3.74 ms per minibatch) but the
-        # wall time does not move (3.03 -> 3.05 ms): the branches compete for the same HBM bandwidth.
-        # "small": only the weight gradients of the 2048-row part of the network (CLS-only last layer, heads), whose kernels are
-        # launch-latency-bound: there the parallel branch does shorten the chain
-        side = os.environ.get("G2048_SIDE_DW", "0").strip().lower()
-        self.side_stream_dw = self.device.type == "cuda" and side in ("1", "true", "yes", "on", "all", "small")
-        self.side_stream_max_rows = 4096 if side == "small" else 0
         # second stage of all gradient reductions in one launch (GradSink); needs the flat gradient bucket
         self.grad_sink = self.device.type == "cuda" and \
             os.environ.get("G2048_GRAD_SINK", "1").strip().lower() not in ("0", "false", "no", "off")
@@ -469,7 +464,7 @@ class PPOTrainer:
             out = sums if (scale is not None or not self.use_amp) else self.scaler.scale(sums)
             # weight / bias / LayerNorm gradients: first-stage partials only, summed into the bucket by ONE launch at the end
             sink = GradSink(self._sink_targets) if (self.grad_sink and self._flat_grad is not None) else None
-            with grad_sink(sink), weight_grads_on_side_stream(self.side_stream_dw, self.side_stream_max_rows):
+            with grad_sink(sink):
                 out.backward(self._loss_selector())
             if sink is not None and sink.written:  # autograd never saw these: point .grad at what the sink wrote
                 for p, v in zip(self._params, self._flat_views):

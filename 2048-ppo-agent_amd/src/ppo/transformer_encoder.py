@@ -7,7 +7,6 @@ out explicitly (pre-norm layers over fused QKV) so that the update path can run 
 without a HIP device, gradients or bf16 autocast every step falls back to the PyTorch operator it mirrors.
 """
 import math
-import os as _os
 
 import torch
 import torch.nn as nn
@@ -18,8 +17,6 @@ from .hip_ops import (Bf16Shadow, ClsLink, FFNLink, _AddLayerNorm, _ClsRows, _At
                       _LinearAddCast, _LinearAddLayerNorm, _LinearReluDropout, _LinearSplitK, _add_norm, _fused_attention_ok, _fused_norm_ok,
                       _linear, _train_bf16, graph_seed_state)
 
-# the last sub-layer's residual add + dropout + bf16 cast as one launch (_LinearAddCast); 0: dropout, add and cast kernels
-_LAST_ADD_FUSED = _os.environ.get("G2048_LAST_ADD_FUSED", "1") != "0"
 
 
 def get_emb(sin_inp: torch.Tensor) -> torch.Tensor:
@@ -135,7 +132,7 @@ class TransformerEncoder(nn.Module):
             link = FFNLink(p) if next_norm is not None else None
             f = _LinearReluDropout.apply(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5], p, link)
             if next_norm is None:
-                if _LAST_ADD_FUSED and sh[6] is not None and layer.linear2.bias is not None:
+                if sh[6] is not None and layer.linear2.bias is not None:
                     # the encoder's output: residual add + dropout + bf16 cast in one launch (the heads read bf16 anyway)
                     return _LinearAddCast.apply(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7], x, p), None
                 f = _linear(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7])

@@ -313,3 +313,17 @@ def test_capture_guard_keeps_the_collector_off_and_restores_it():
         finally:
             gc.enable()
     assert seen.during_capture == 0
+
+
+def test_private_torch_interfaces_exist_with_the_expected_shapes(monkeypatch):
+    """src/ppo/torch_compat.py: every private PyTorch interface the device update path uses is present in this torch and
+    behaves as the callers assume; a missing one produces ONE error that names the torch version and the interface."""
+    from src.ppo import torch_compat
+
+    assert torch_compat.problems() == []
+    torch_compat.check()
+    monkeypatch.setattr(torch_compat, "_checked", False)
+    monkeypatch.delattr(torch, "_addmm_activation")
+    with pytest.raises(torch_compat.TorchInterfaceError) as e:
+        torch_compat.check()
+    assert torch.__version__ in str(e.value) and "_addmm_activation" in str(e.value)
