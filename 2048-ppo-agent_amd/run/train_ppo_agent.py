@@ -74,7 +74,7 @@ def main():
         value_loss_coef=t["value_loss_coef"], entropy_coef=t["entropy_coef"], max_grad_norm=t["max_grad_norm"],
         target_kl=t["target_kl"], use_action_mask=t["use_action_mask"], device=device,
         mixed_precision=t["mixed_precision"], max_samples_per_epoch=t["max_samples_per_epoch"],
-        shuffle_on_reset=t["shuffle_on_reset"], rollout_amp=bool(t.get("rollout_amp", False)))
+        shuffle_on_reset=t["shuffle_on_reset"], rollout_amp=t.get("rollout_amp"))  # None: bf16 rollout when mixed_precision is bfloat16 (G2048_ROLLOUT_FP32=1: fp32)
     if t.get("resume_from_checkpoint"):
         if not os.path.exists(t["resume_from_checkpoint"]):
             raise FileNotFoundError(f"Checkpoint file not found: {t['resume_from_checkpoint']}")

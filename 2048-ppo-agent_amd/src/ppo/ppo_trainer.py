@@ -35,6 +35,19 @@ from .hip_ops import Bf16Shadow, GradSink, grad_sink, graph_seed_state
 logger = logging.getLogger(__name__)
 
 
+def resolve_rollout_amp(rollout_amp, mixed_precision, environ=None) -> bool:
+    """Whether the rollout forward runs in the update's autocast dtype: an explicit argument wins; else G2048_ROLLOUT_AMP=0/1
+    (round-2 switch); else bf16 mixed precision implies the bf16 rollout unless G2048_ROLLOUT_FP32=1 (the reference's fp32)."""
+    if rollout_amp is not None:
+        return bool(rollout_amp)
+    environ = os.environ if environ is None else environ
+    on = ("1", "true", "yes", "on")
+    env_amp = environ.get("G2048_ROLLOUT_AMP", "").strip().lower()
+    if env_amp:
+        return env_amp in on
+    return mixed_precision == "bfloat16" and environ.get("G2048_ROLLOUT_FP32", "0").strip().lower() not in on
+
+
 class _NullWriter:
     """Stand-in when tensorboard is not installed: same calls, no output."""
 
@@ -198,13 +211,15 @@ class PPOTrainer:
             self.scaler, self.amp_dtype = None, None
             if mixed_precision is not None:
                 logger.warning("Mixed precision requested but device is %s; disabled.", self.device.type)
-        # The reference rolls out in fp32 (torch_action_wrapper.py has no autocast) and that is the default here too.
-        # rollout_amp=True runs the rollout forward in the update's autocast dtype -- for bfloat16 and the reference's
-        # default model shape that is the fused MFMA encoder kernel (g2048_policy_encoder).  The reference's unmodified
-        # run/train_ppo_agent.py cannot pass the extra argument, so None (the default) takes it from the environment:
-        # G2048_ROLLOUT_AMP=1 switches the fast path on for a drop-in run.
-        if rollout_amp is None:
-            rollout_amp = os.environ.get("G2048_ROLLOUT_AMP", "0").strip().lower() in ("1", "true", "yes", "on")
+        # Rollout precision.  The reference rolls out in fp32 (its torch_action_wrapper.py has no autocast) while its trainer
+        # config sets mixed_precision: bfloat16 for the update.  Here ``mixed_precision="bfloat16"`` implies the bf16 rollout
+        # forward as well -- for the reference's default model shape that is the fused MFMA encoder kernel
+        # (g2048_policy_encoder), 12x the collect rate of the fp32 module forward -- so that an unmodified
+        # run/train_ppo_agent.py gets the fast path.  The numeric deviation (rollout log-probs / values at bf16-autocast
+        # distance from the fp32 forward, i.e. the same distance the update's own forward has) is documented in
+        # INTEGRATION.md.  ``rollout_amp=False`` or G2048_ROLLOUT_FP32=1 keeps the reference's fp32 rollout;
+        # G2048_ROLLOUT_AMP=0/1 (round-2 switch) is still honoured.
+        rollout_amp = resolve_rollout_amp(rollout_amp, mixed_precision)
         self.rollout_amp = bool(rollout_amp) and self.use_amp
         # How collect_rollouts gathers experience.  "episodes" (default) is the reference: lock-step batches of complete
         # episodes (src/runs/batch_runner.py:117), finished envs idle until the slowest one ends.  "fixed_horizon" is the

@@ -16,8 +16,11 @@ Also on the JSON line (measured AFTER the timed region; none of it is part of `v
   hip_graph        whether the update really replayed its captured hipGraph (false = the slower eager fallback ran)
   frozen_policy    the same iteration with the learning rate at 0: does not depend on how far the policy has trained
   fixed_horizon    the throughput mode (per-lane auto-reset, fixed horizon, bootstrapped GAE): full PPO iterations
-  drop_in_fp32_rollout  collect phase of the reference-default fp32 rollout (what an unmodified CLI run gets unless
-                   G2048_ROLLOUT_AMP=1), bounded sample
+  value_frozen_policy  = frozen_policy.value, on the top level because `value` itself grows with --steps (the policy learns
+                   during the run and episodes get longer)
+  drop_in_default  collect phase as an unmodified run/train_ppo_agent.py gets it: PPOTrainer(rollout_amp=None) with the
+                   reference's mixed_precision: bfloat16 -> bf16 rollout through the fused encoder
+  drop_in_fp32_rollout  collect phase of the reference's own fp32 rollout forward (G2048_ROLLOUT_FP32=1), bounded sample
   roofline         the board-step kernel (g2048_step, 50 algorithmic bytes per env-step) at a saturating launch of
                    2^24 boards, HIP events on its launch stream; `valu` = the same launch against the vector-ALU issue peak
   in_loop          the fused policy-step kernel as it ran inside the timed region (HIP events around every launch)
@@ -98,17 +101,20 @@ def step_kernel_roofline(dev, boards_per_launch: int, launches: int = 20):
     torch.cuda.synchronize()
     us = start.elapsed_time(end) * 1e3 / launches
     gbs = STEP_BYTES * B / (us * 1e-6) / 1e9
-    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE x2
-    # gfx950 correction), scaled to this launch size; null if that profile is not in the tree
-    traffic = None
+    # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 around the process).  The number is the
+    # committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE x2 gfx950 correction) of the same kernel,
+    # scaled to this launch size; `traffic_source` says so.  null if that profile is not in the tree
+    traffic, traffic_source = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "step_kernel_pmc_latest.json")))
         traffic = round(pmc["hbm_bytes_per_env_step"] * B)
+        traffic_source = f"profiles/step_kernel_pmc_latest.json ({pmc.get('measured_in', 'round 1')}, kernel unchanged since; not measured in this run)"
     except Exception:
         pass
     ginstr = STEP_VALU_PER_WAVE * (B / 64) / (us * 1e-6) / 1e9
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "k_step (g2048_step)",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": "k_step (g2048_step)",
             "boards_per_launch": B, "launch_us": round(us, 2), "algorithmic_bytes_per_env_step": STEP_BYTES,
             "live_fraction": round(live, 3),
             "valu": {"instr_per_wave": STEP_VALU_PER_WAVE, "achieved_Ginstr_s": round(ginstr, 1),
@@ -427,6 +433,7 @@ def main():
                                 "hip_graph": bool(m.get("hip_graph", False)),
                                 "what": "the headline iteration with max_lr = 0 (random-init policy stays put: same work per "
                                         "iteration whatever --steps is); 1 warm-up + 1 timed iteration"}
+        out["value_frozen_policy"] = out["frozen_policy"]["value"]
         del fr
         torch.cuda.empty_cache()
         fx = make_trainer(args.workload, rollout_mode="fixed_horizon", rollout_horizon=args.horizon)
@@ -459,7 +466,23 @@ def main():
                                "what": f"fused random-policy rollout of {args.boards} boards, complete episodes, "
                                        "trajectory written to HBM, no policy network"}
             if args.workload == "transformer65536":
-                # what an unmodified reference CLI run gets by default: the fp32 PyTorch forward in the rollout
+                # what an unmodified reference CLI run gets: rollout_amp=None + mixed_precision bfloat16 -> the fused bf16 encoder
+                dd = PPOTrainer(PPOAgent(**MODEL_CFG), BatchRunner(init_seed=0, rng_mode="partitionable", device=dev),
+                                RolloutBuffer(31, 16, 4), OPTIM_CFG, max_steps=500000, device=dev,
+                                log_dir=os.path.join("/tmp", f"g2048_bench_logs_{rank}"), **TRAINER_CFG)
+                dd.collect_rollouts(args.boards, 1)  # warm
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                dd.collect_rollouts(args.boards, 1)
+                torch.cuda.synchronize()
+                out["drop_in_default"] = {
+                    "value": round(dd.last_rollout_stats["timesteps"] / (time.perf_counter() - t1), 1),
+                    "unit": "env-steps/sec (collect phase only)", "boards": args.boards, "rollout_amp": dd.rollout_amp,
+                    "what": "PPOTrainer(rollout_amp=None) as the reference's run/train_ppo_agent.py constructs it: mixed_precision "
+                            "bfloat16 implies the bf16 rollout (fused encoder); G2048_ROLLOUT_FP32=1 restores the fp32 rollout"}
+                del dd
+                torch.cuda.empty_cache()
+                # the reference's own rollout precision: the fp32 PyTorch forward
                 fb = min(8192, args.boards)
                 r32 = BatchRunner(init_seed=0, rng_mode="partitionable", device=dev,
                                   act_fn=TorchActionFunction(agent, use_mask=True, device=dev))
@@ -470,8 +493,8 @@ def main():
                 torch.cuda.synchronize()
                 out["drop_in_fp32_rollout"] = {
                     "value": round(n32 / (time.perf_counter() - t1), 1), "unit": "env-steps/sec (collect phase only)",
-                    "boards": fb, "what": "reference-default fp32 rollout forward in PyTorch (no fused encoder): what "
-                                          "run/train_ppo_agent.py gets unless G2048_ROLLOUT_AMP=1 is set; bounded sample"}
+                    "boards": fb, "what": "the reference's fp32 rollout forward in PyTorch (no fused encoder): what "
+                                          "run/train_ppo_agent.py gets with G2048_ROLLOUT_FP32=1; bounded sample"}
             if world == 1 and args.workload == "transformer65536":
                 ml = make_trainer("mlp4096")
                 n, s, m = run_iterations(ml, 4096, 1, 3)

@@ -327,3 +327,15 @@ def test_private_torch_interfaces_exist_with_the_expected_shapes(monkeypatch):
     with pytest.raises(torch_compat.TorchInterfaceError) as e:
         torch_compat.check()
     assert torch.__version__ in str(e.value) and "_addmm_activation" in str(e.value)
+
+
+def test_rollout_precision_default():
+    """mixed_precision bfloat16 implies the bf16 rollout (what the unmodified reference CLI gets); G2048_ROLLOUT_FP32=1 and an
+    explicit argument restore the reference's fp32 rollout; the round-2 switch G2048_ROLLOUT_AMP still decides when set."""
+    from src.ppo.ppo_trainer import resolve_rollout_amp as r
+
+    assert r(None, "bfloat16", {}) is True
+    assert r(None, "bfloat16", {"G2048_ROLLOUT_FP32": "1"}) is False
+    assert r(None, None, {}) is False and r(None, "float16", {}) is False
+    assert r(False, "bfloat16", {}) is False and r(True, None, {"G2048_ROLLOUT_FP32": "1"}) is True
+    assert r(None, "bfloat16", {"G2048_ROLLOUT_AMP": "0"}) is False and r(None, None, {"G2048_ROLLOUT_AMP": "1"}) is True
