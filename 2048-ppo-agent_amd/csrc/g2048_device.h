@@ -284,10 +284,17 @@ G_DEV u32 board_legal(const Board &bd) {
 // jax.random.choice spawn: uniformly chosen empty cell (row-major order), value 1 (p=.9) or 2.
 template <int MODE>
 G_DEV void board_spawn(Board &bd, u32 k0, u32 k1) {
+#ifdef G2048_RNG_STUB
+    // Diagnostic build only (tools/step_rng_floor.py; never compiled into the product library): the two random words of a
+    // spawn are taken from the key as they are instead of through split + 2 x bits = four threefry2x32 blocks.  Same bytes
+    // per env-step, board logic untouched: what k_step would cost if the reference's RNG schedule were free.
+    const u32 bpos = k0, bval = k1;
+#else
     u32 p0, p1, v0, v1;
     split2<MODE>(k0, k1, p0, p1, v0, v1);
     const u32 bpos = bits_scalar<MODE>(p0, p1);
     const u32 bval = bits_scalar<MODE>(v0, v1);
+#endif
     // empties per row and running totals (row-major)
     u32 z[4], c[4];
     for (int i = 0; i < 4; ++i) z[i] = tile_bits(bd.r[i]) ^ 0x80808080u;

@@ -112,11 +112,23 @@ def step_kernel_roofline(dev, boards_per_launch: int, launches: int = 20):
     except Exception:
         pass
     ginstr = STEP_VALU_PER_WAVE * (B / 64) / (us * 1e-6) / 1e9
+    # the same kernel with the reference's RNG schedule stubbed out (diagnostic build, tools/step_rng_floor.py): what the board
+    # logic alone reaches; committed measurement, not repeated in this run
+    rng_floor = {}
+    try:
+        fl = json.load(open(os.path.join(ROOT, "profiles", "round3_step_rng_floor.json")))
+        rng_floor = {"rng_floor_frac": fl["rng_floor_frac"],
+                     "rng_floor_source": f"profiles/round3_step_rng_floor.json: k_step with -DG2048_RNG_STUB (no threefry, same bytes) "
+                                         f"{fl['rng_stub']['launch_us']} us vs {fl['real']['launch_us']} us for the real kernel at "
+                                         f"{fl['boards_per_launch']} boards; the 4 threefry2x32 blocks per step that the bit-exact "
+                                         f"jax.random stream prescribes are the difference"}
+    except Exception:
+        pass
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "k_step (g2048_step)",
             "boards_per_launch": B, "launch_us": round(us, 2), "algorithmic_bytes_per_env_step": STEP_BYTES,
-            "live_fraction": round(live, 3),
+            "live_fraction": round(live, 3), **rng_floor,
             "valu": {"instr_per_wave": STEP_VALU_PER_WAVE, "achieved_Ginstr_s": round(ginstr, 1),
                      "peak_Ginstr_s": round(VALU_PEAK_GINSTR, 1), "frac": round(ginstr / VALU_PEAK_GINSTR, 4),
                      "what": "wave64 vector instructions issued per second vs 1024 SIMDs x 2.4 GHz / 2 cycles; the kernel's mix "
