@@ -74,6 +74,9 @@ SIGNATURES = {
     "g2048_relu_dropout_fwd": [_vp, _vp, _i64, _i32, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_relu_dropout_bwd_workspace_floats": [_i64, _i32],
     "g2048_relu_dropout_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, C.c_float, _vp],
+    "g2048_cls_tail_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_cls_tail_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_dweight_t": [_vp, _i32, _i64, _i64, _i32, _vp],
     "g2048_opt_workspace_floats": [_i32],
     "g2048_opt_step": [_vp, _i32, _vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _i32, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp, _vp],
 }
@@ -628,3 +631,120 @@ def gather_minibatch(idx, boards, actions, masks, logp, adv, ret, out=None):
         _dev(out["old_lp"], f32, M, "o_logp"), _dev(out["adv"], f32, M, "o_adv"), _dev(out["ret"], f32, M, "o_ret"), _stream()),
         "g2048_gather_minibatch")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the 2048-row tail of the update (csrc/g2048_tail.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+TAIL_MASK_TILES = 96
+DW_MAX_JOBS = 16
+
+
+class TailWeights(C.Structure):
+    _fields_ = [(n, _vp) for n in ("wo", "w1", "w2", "a1", "a2", "a3", "c1", "c2", "c3", "bo", "b1", "b2", "ab1", "ab2", "cb1", "cb2",
+                                   "ln_g", "ln_b")]
+
+
+class TailWeightsT(C.Structure):
+    _fields_ = [(n, _vp) for n in ("woT", "w1T", "w2T", "a1T", "a2T", "a3", "c1T", "c2T", "c3", "ln_g")]
+
+
+class TailSaved(C.Structure):
+    _fields_ = [(n, _vp) for n in ("x_mid", "mean", "rstd", "masks", "oT", "h2T", "uT", "featsT", "a1T", "a2T", "c1T", "c2T")] \
+        + [("ld", _i64)]
+
+
+class TailGrads(C.Structure):
+    _fields_ = [(n, _vp) for n in ("daoT", "dzT", "df2T", "da1T", "da2T", "dlT", "dc1T", "dc2T", "dvT", "ln_partial")]
+
+
+class DwJob(C.Structure):
+    _fields_ = [("dyT", _vp), ("xT", _vp), ("dw", _vp), ("db", _vp), ("N", C.c_int32), ("K", C.c_int32)]
+
+
+_TAIL_SAVED_ROWS = dict(oT=256, h2T=256, uT=1024, featsT=256, a1T=512, a2T=512, c1T=512, c2T=512)
+_TAIL_GRAD_ROWS = dict(daoT=256, dzT=1024, df2T=256, da1T=512, da2T=512, dlT=32, dc1T=512, dc2T=512, dvT=32)
+
+
+class TailBuffers:
+    """Device buffers of one g2048_cls_tail_fwd / _bwd pair for M rows (allocated once per minibatch size and reused: every
+    element that is read is rewritten by each forward / backward; dlT / dvT rows that are never written stay zero)."""
+
+    def __init__(self, M: int, device):
+        bf = torch.bfloat16
+        self.M, self.blocks = int(M), (int(M) + 31) // 32
+        self.ld = 32 * self.blocks
+        self.slices = next(s for s in (8, 4, 2, 1) if self.ld % (16 * s) == 0)
+        z = lambda *shape, dtype=bf: torch.zeros(shape, dtype=dtype, device=device)
+        self.saved = dict(x_mid=z(self.M, 256, dtype=f32), mean=z(self.M, dtype=f32), rstd=z(self.M, dtype=f32),
+                          masks=z(self.blocks, TAIL_MASK_TILES, 64, dtype=torch.int16))
+        self.saved.update({k: z(rows, self.ld) for k, rows in _TAIL_SAVED_ROWS.items()})
+        self.grads = {k: z(rows, self.ld) for k, rows in _TAIL_GRAD_ROWS.items()}
+        self.grads["ln_partial"] = z(self.blocks, 512, dtype=f32)
+        self.saved_c = TailSaved(*[self.saved[n].data_ptr() for n, _ in TailSaved._fields_[:-1]], self.ld)
+        self.grads_c = TailGrads(*[self.grads[n].data_ptr() for n, _ in TailGrads._fields_])
+        self.logits, self.values = z(self.M, 4, dtype=f32), z(self.M, dtype=f32)
+        self.d_o, self.dx_cls = z(self.M, 256), z(self.M, 256, dtype=f32)
+        # weight-gradient partials [slices][N][K] / [slices][N] per Linear: (dyT key, xT key, N (padded to 32), K, has bias)
+        self.dw_spec = dict(wo=("daoT", "oT", 256, 256, True), w1=("dzT", "h2T", 1024, 256, True), w2=("df2T", "uT", 256, 1024, True),
+                            a1=("da1T", "featsT", 512, 256, True), a2=("da2T", "a1T", 512, 512, True), a3=("dlT", "a2T", 32, 512, False),
+                            c1=("dc1T", "featsT", 512, 256, True), c2=("dc2T", "c1T", 512, 512, True), c3=("dvT", "c2T", 32, 512, False))
+        self.dw = {k: z(self.slices, n, kk, dtype=f32) for k, (_, _, n, kk, _) in self.dw_spec.items()}
+        self.db = {k: z(self.slices, n, dtype=f32) for k, (_, _, n, _, b) in self.dw_spec.items() if b}
+
+
+def _ptr_struct(cls, tensors: dict, dtypes: dict):
+    vals = []
+    for name, _ in cls._fields_:
+        t = tensors[name]
+        want = dtypes.get(name, torch.bfloat16)
+        if not t.is_cuda or t.dtype != want or not t.is_contiguous() or t.data_ptr() % 16:
+            raise NativeError(f"{cls.__name__}.{name}: expected a contiguous, 16-byte aligned {want} device tensor, got {t.dtype} "
+                              f"on {t.device}")
+        vals.append(t.data_ptr())
+    return cls(*vals)
+
+
+_TAIL_F32 = {n: f32 for n in ("bo", "b1", "b2", "ab1", "ab2", "cb1", "cb2", "ln_g", "ln_b")}
+
+
+def tail_weights(tensors: dict) -> TailWeights:
+    """bf16 weights (nn.Linear layout) + f32 biases / norm2 parameters by field name -> the C struct (the caller keeps them alive)."""
+    return _ptr_struct(TailWeights, tensors, _TAIL_F32)
+
+
+def tail_weights_t(tensors: dict) -> TailWeightsT:
+    return _ptr_struct(TailWeightsT, tensors, _TAIL_F32)
+
+
+def cls_tail_fwd(o, x_cls_ptr: int, x_row_stride: int, W: TailWeights, buf: TailBuffers, eps: float, p_drop: float, seed: int,
+                 seed_state: int = 0):
+    """o bf16 [M, 256]; x_cls_ptr: raw device address of f32 rows (element stride x_row_stride) the caller keeps alive.
+    -> (buf.logits f32 [M, 4], buf.values f32 [M])."""
+    _check(load().g2048_cls_tail_fwd(_dev(o, torch.bfloat16, 256 * buf.M, "o"), x_cls_ptr, int(x_row_stride), C.byref(W),
+                                     C.byref(buf.saved_c), buf.logits.data_ptr(), buf.values.data_ptr(), buf.M, float(eps),
+                                     float(p_drop), int(seed), seed_state or None, _stream()), "g2048_cls_tail_fwd")
+    return buf.logits, buf.values
+
+
+def cls_tail_bwd(dlogits, dvalues, WT: TailWeightsT, buf: TailBuffers, p_drop: float, seed: int, seed_state: int = 0):
+    """-> (buf.d_o bf16 [M, 256], buf.dx_cls f32 [M, 256]); dY^T of every Linear and the LayerNorm partials land in buf.grads."""
+    _check(load().g2048_cls_tail_bwd(_dev(dlogits, f32, 4 * buf.M, "dlogits"), _dev(dvalues, f32, buf.M, "dvalues"), C.byref(WT),
+                                     C.byref(buf.saved_c), C.byref(buf.grads_c), buf.d_o.data_ptr(), buf.dx_cls.data_ptr(), buf.M,
+                                     float(p_drop), int(seed), seed_state or None, _stream()), "g2048_cls_tail_bwd")
+    return buf.d_o, buf.dx_cls
+
+
+def dweight_t(jobs, ld: int, m: int, slices: int):
+    """jobs: list of (dyT bf16 [N, ld], xT bf16 [K, ld], dw f32 [slices, N, K], db f32 [slices, N] or None)."""
+    recs = []
+    for dyT, xT, dw, db in jobs:
+        N, K = dyT.shape[0], xT.shape[0]
+        for t, dt, name in ((dyT, torch.bfloat16, "dyT"), (xT, torch.bfloat16, "xT"), (dw, f32, "dw")):
+            if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+                raise NativeError(f"dweight_t: {name} must be a contiguous {dt} device tensor")
+        if dyT.shape[1] != ld or xT.shape[1] != ld or dw.numel() != slices * N * K or (db is not None and db.numel() != slices * N):
+            raise NativeError(f"dweight_t: shapes {tuple(dyT.shape)} x {tuple(xT.shape)} -> {tuple(dw.shape)} do not fit ld={ld}")
+        recs.append(DwJob(dyT.data_ptr(), xT.data_ptr(), dw.data_ptr(), None if db is None else _dev(db, f32, slices * N, "db"), N, K))
+    arr = (DwJob * len(recs))(*recs)
+    _check(load().g2048_dweight_t(C.cast(arr, _vp), len(recs), int(ld), int(m), int(slices), _stream()), "g2048_dweight_t")

@@ -881,3 +881,129 @@ def _linear(x: torch.Tensor, weight: torch.Tensor, bias, wb=None, bb=None, relu:
     else:
         y = F.linear(x, weight, bias)
     return F.relu(y) if relu else y
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the 2048-row tail of the update as one autograd node (csrc/g2048_tail.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+TAIL_PARAM_ORDER = ("wo", "bo", "ln_g", "ln_b", "w1", "b1", "w2", "b2", "a1", "ab1", "a2", "ab2", "a3", "c1", "cb1", "c2", "cb2", "c3")
+_TAIL_BIAS_OF = dict(wo="bo", w1="b1", w2="b2", a1="ab1", a2="ab2", c1="cb1", c2="cb2")
+_TAIL_REAL_ROWS = dict(a3=4, c3=1)  # Linears whose dY^T buffer is padded to 32 rows
+
+
+class TailBufferCache(dict):
+    """Per-module cache of ``native.TailBuffers`` (device buffers + ctypes structs holding raw pointers): never copied or
+    pickled with the module -- a copy of an agent starts with an empty cache."""
+
+    def __deepcopy__(self, memo):
+        return TailBufferCache()
+
+    def __reduce__(self):
+        return (TailBufferCache, ())
+
+
+class TailPlan:
+    """Everything ``_ClsTailHeads`` needs besides its tensor inputs: the f32 master parameters by field name (``TAIL_PARAM_ORDER``),
+    their bf16 shadows (dense for the forward, transposed for the backward) and the buffer cache of the owning module."""
+
+    def __init__(self, params: dict, dense: dict, transposed: dict, buffer_cache: dict, eps: float, p_drop: float):
+        self.params, self.dense, self.transposed, self.cache = params, dense, transposed, buffer_cache
+        self.eps, self.p_drop = float(eps), float(p_drop)
+
+    def buffers(self, M: int, device):
+        from ..g2048 import native as nv
+
+        key = (int(M), str(device))
+        buf = self.cache.get(key)
+        if buf is None or getattr(buf, "busy", False):
+            # busy: a forward whose backward never ran still owns the cached set (e.g. two forwards before one backward): this
+            # call gets a private one instead of overwriting what that backward would read
+            fresh = nv.TailBuffers(M, device)
+            if buf is None:
+                self.cache[key] = fresh
+            buf = fresh
+        return buf
+
+    def fwd_struct(self):
+        from ..g2048 import native as nv
+
+        t = {k: self.dense[k] for k in ("wo", "w1", "w2", "a1", "a2", "a3", "c1", "c2", "c3")}
+        t.update({k: self.params[k].detach() for k in ("bo", "b1", "b2", "ab1", "ab2", "cb1", "cb2", "ln_g", "ln_b")})
+        return nv.tail_weights(t), t
+
+    def bwd_struct(self):
+        from ..g2048 import native as nv
+
+        t = {k + "T": self.transposed[k] for k in ("wo", "w1", "w2", "a1", "a2", "c1", "c2")}
+        t.update(a3=self.dense["a3"], c3=self.dense["c3"], ln_g=self.params["ln_g"].detach())
+        return nv.tail_weights_t(t), t
+
+
+class _ClsTailHeads(torch.autograd.Function):
+    """``(logits, values)`` from the CLS rows after the last layer's attention: out_proj + dropout + residual + LayerNorm, the
+    feed-forward block + dropout + residual, actor and critic heads -- ``g2048_cls_tail_fwd`` forward, ``g2048_cls_tail_bwd`` +
+    ``g2048_dweight_t`` backward: 3 launches where the unfused nodes needed ~55.  o bf16 [M, 1, 256] (attention output), x f32
+    [M, 1, 256] (CLS rows of the residual stream, read in place through their row stride); ``params``: the f32 masters in
+    ``TAIL_PARAM_ORDER`` (inputs only so that autograd can take their gradients when no ``GradSink`` is active).
+    One minibatch in flight per module: the buffers between forward and backward are cached per minibatch size."""
+
+    @staticmethod
+    def forward(ctx, o, x, plan, *params):
+        from ..g2048 import native as nv
+
+        M = o.shape[0]
+        o2 = o.reshape(M, 256).contiguous()
+        xr, row_stride = _residual_rows(x)
+        buf = plan.buffers(M, o.device)
+        W, keep = plan.fwd_struct()
+        seed = _seed_pair(o2, plan.p_drop)
+        logits, values = nv.cls_tail_fwd(o2, xr.data_ptr(), row_stride, W, buf, plan.eps, plan.p_drop, *seed)
+        buf.busy = True
+        ctx.plan, ctx.buf, ctx.seed, ctx.keep = plan, buf, seed, (keep, xr, o2)
+        ctx.x_shape, ctx.o_shape = tuple(x.shape), tuple(o.shape)
+        ctx.set_materialize_grads(False)
+        return logits, values.view(M, 1)
+
+    @staticmethod
+    def backward(ctx, dlogits, dvalues):
+        from ..g2048 import native as nv
+
+        plan, buf = ctx.plan, ctx.buf
+        M = buf.M
+        dev = buf.logits.device
+        dlogits = torch.zeros((M, 4), dtype=torch.float32, device=dev) if dlogits is None else dlogits.float().contiguous()
+        dvalues = torch.zeros(M, dtype=torch.float32, device=dev) if dvalues is None else dvalues.float().reshape(M).contiguous()
+        WT, keep_t = plan.bwd_struct()
+        d_o, dx = nv.cls_tail_bwd(dlogits, dvalues, WT, buf, plan.p_drop, *ctx.seed)
+        jobs = []
+        for k, (dy, xt, _n, _k, has_b) in buf.dw_spec.items():
+            jobs.append((buf.grads[dy], buf.saved[xt], buf.dw[k], buf.db[k] if has_b else None))
+        nv.dweight_t(jobs, buf.ld, buf.ld, buf.slices)
+        buf.busy = False
+        P = plan.params
+        sink = _sink_for(*[P[k] for k in TAIL_PARAM_ORDER])
+        S = buf.slices
+        grads = {}
+        for k, (_dy, _xt, n_pad, kk, has_b) in buf.dw_spec.items():
+            n_real = _TAIL_REAL_ROWS.get(k, n_pad)
+            if sink is not None:
+                sink.add(P[k], buf.dw[k], n_pad * kk, n_real * kk, S)
+                if has_b:
+                    sink.add(P[_TAIL_BIAS_OF[k]], buf.db[k], n_pad, n_pad, S)
+            else:
+                grads[k] = buf.dw[k].sum(0)[:n_real].to(P[k].dtype)
+                if has_b:
+                    grads[_TAIL_BIAS_OF[k]] = buf.db[k].sum(0).to(P[_TAIL_BIAS_OF[k]].dtype)
+        lnp = buf.grads["ln_partial"]
+        if sink is not None:
+            sink.add(P["ln_g"], lnp, 512, 256, buf.blocks)
+            sink.add(P["ln_b"], lnp[:, 256:], 512, 256, buf.blocks)
+        else:
+            s = lnp.sum(0)
+            grads["ln_g"], grads["ln_b"] = s[:256].to(P["ln_g"].dtype), s[256:].to(P["ln_b"].dtype)
+        # (views of the cached buffers: the nodes that consume them run in this same backward pass)
+        do_out = d_o.view(ctx.o_shape) if ctx.needs_input_grad[0] else None
+        dx_out = dx.view(ctx.x_shape) if ctx.needs_input_grad[1] else None
+        if sink is not None:
+            return (do_out, dx_out, None) + (None,) * len(TAIL_PARAM_ORDER)
+        return (do_out, dx_out, None) + tuple(grads[k] for k in TAIL_PARAM_ORDER)

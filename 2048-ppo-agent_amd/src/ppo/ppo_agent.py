@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from torch.distributions import Categorical
 
 from ..env_definitions import ACTION_DIM, OBS_DIM
-from .hip_ops import Bf16Shadow, _linear, _train_bf16
+from .hip_ops import TAIL_PARAM_ORDER, Bf16Shadow, TailBufferCache, TailPlan, _ClsTailHeads, _linear, _train_bf16
 from .transformer_encoder import TransformerEncoder
 
 
@@ -114,6 +114,50 @@ class PPOAgent(_ActorCritic):
         if self.transformer.embed_boards_ok(observations, w):
             return self.transformer.forward_boards(observations, w, reduction=self.reduction)
         return self.transformer(self.embed(observations), reduction=self.reduction)
+
+    # ---- the fused CLS tail of the update path (hip_ops._ClsTailHeads): last layer's out_proj .. both heads in one node
+    def _tail_heads_ok(self) -> bool:
+        def std(head, n_out):
+            m = list(head)
+            return (len(m) == 5 and isinstance(m[0], nn.Linear) and type(m[1]) is nn.ReLU and isinstance(m[2], nn.Linear)
+                    and type(m[3]) is nn.ReLU and isinstance(m[4], nn.Linear) and m[4].bias is None and m[0].bias is not None
+                    and m[2].bias is not None and tuple(m[0].weight.shape) == (512, 256) and tuple(m[2].weight.shape) == (512, 512)
+                    and tuple(m[4].weight.shape) == (n_out, 512))
+
+        return (self.reduction == "cls" and self.action_dim == 4 and std(self.actor, 4) and std(self.critic, 1)
+                and all(p.dtype == torch.float32 for p in self.parameters()))
+
+    def _tail_heads(self, o, x_cls, params, dense, transposed, eps, p_drop):
+        """Closure handed to the encoder (``TransformerEncoder.encode``): adds the heads' parameters and shadows to the last
+        layer's and runs the node."""
+        a, c = list(self.actor), list(self.critic)
+        lins = [a[0], a[2], a[4], c[0], c[2], c[4]]
+        if self._head_shadow is None or not self._head_shadow.transposed:
+            ps = [q for m in lins for q in (m.weight, m.bias) if q is not None]  # a1.w a1.b a2.w a2.b a3.w c1.w c1.b c2.w c2.b c3.w
+            self._head_shadow = Bf16Shadow(ps, transposed=[0, 2, 5, 7])
+        v = self._head_shadow()
+        tv = self._head_shadow.tviews
+        params = dict(params, a1=a[0].weight, ab1=a[0].bias, a2=a[2].weight, ab2=a[2].bias, a3=a[4].weight, c1=c[0].weight,
+                      cb1=c[0].bias, c2=c[2].weight, cb2=c[2].bias, c3=c[4].weight)
+        dense = dict(dense, a1=v[0], a2=v[2], a3=v[4], c1=v[5], c2=v[7], c3=v[9])
+        transposed = dict(transposed, a1=tv[0], a2=tv[2], c1=tv[5], c2=tv[7])
+        if not hasattr(self, "_tail_buffers"):
+            self._tail_buffers = TailBufferCache()
+        plan = TailPlan(params, dense, transposed, self._tail_buffers, eps, p_drop)
+        return _ClsTailHeads.apply(o, x_cls, plan, *[params[k] for k in TAIL_PARAM_ORDER])
+
+    def forward(self, observations: torch.Tensor, action_mask: torch.Tensor = None):
+        w = self.input_embedding.weight
+        if self.transformer.embed_boards_ok(observations, w) and self._tail_heads_ok():
+            out = self.transformer.forward_boards(observations, w, reduction=self.reduction, tail_heads=self._tail_heads)
+            if isinstance(out, tuple):
+                logits, values = out
+            else:
+                logits, values = self._heads(out)
+            if action_mask is not None:
+                logits = logits - 1e8 * (1 - action_mask.float())
+            return logits, values
+        return super().forward(observations, action_mask)
 
 
 class MLPAgent(_ActorCritic):

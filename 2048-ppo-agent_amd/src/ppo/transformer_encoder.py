@@ -86,12 +86,15 @@ class TransformerEncoder(nn.Module):
             for l in layers:
                 ps += [l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, l.self_attn.out_proj.weight,
                        l.self_attn.out_proj.bias, l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias]
-            self._shadow = Bf16Shadow(ps, transposed=[8 * i + 6 for i in range(len(layers))])
+            last = len(layers) - 1
+            # [in, out] copies: linear2 of every layer (masked input-gradient GEMM); out_proj and linear1 of the LAST layer (the
+            # fused CLS tail's backward, g2048_cls_tail_bwd)
+            self._shadow = Bf16Shadow(ps, transposed=[8 * i + 6 for i in range(len(layers))] + [8 * last + 2, 8 * last + 4])
         v = self._shadow()
         return [v[8 * i:8 * i + 8] + [self._shadow.tviews[8 * i + 6]] for i in range(len(layers))]
 
     def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor, h: torch.Tensor, next_norm,
-               cls_only: bool = False, sh=(None,) * 9, cls_link_out=None, cls_link_in=None):
+               cls_only: bool = False, sh=(None,) * 9, cls_link_out=None, cls_link_in=None, tail_heads=None):
         """One pre-norm encoder layer.  ``h`` = norm1(x), already computed (by the previous layer's tail); returns
         (x_out, next_norm(x_out)) so that every residual add + dropout + LayerNorm is one fused kernel
         (``_add_norm``); ``next_norm`` None: (x_out, None).  With ``cls_only`` only the CLS row of the output is
@@ -123,6 +126,18 @@ class TransformerEncoder(nn.Module):
                 q, k, v = qkv.view(B, S, 3, H, D // H).unbind(dim=2)
                 a = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
                                                    dropout_p=p).transpose(1, 2).reshape(B, S, D)
+        if cls_only and tail_heads is not None and sh[0] is not None and a.dtype == torch.bfloat16 and _fused_norm_ok(x, None) \
+                and layer.linear1.out_features == 1024 and D == 256:
+            # update path, CLS-only last layer: everything from out_proj to the heads' outputs is ONE node (g2048_cls_tail_fwd/bwd);
+            # the caller's closure adds the heads' parameters and returns (logits, values)
+            i_last = len(self.encoder.layers) - 1
+            tv = self._shadow.tviews
+            n2 = layer.norm2
+            return tail_heads(a, x, dict(wo=attn.out_proj.weight, bo=attn.out_proj.bias, ln_g=n2.weight, ln_b=n2.bias,
+                                         w1=layer.linear1.weight, b1=layer.linear1.bias, w2=layer.linear2.weight,
+                                         b2=layer.linear2.bias),
+                              dict(wo=sh[2], w1=sh[4], w2=sh[6]), dict(wo=tv[8 * i_last + 2], w1=tv[8 * i_last + 4], w2=sh[8]),
+                              n2.eps, p), None
         if sh[0] is not None and a.dtype == torch.bfloat16 and _fused_norm_ok(x, None) \
                 and layer.linear1.out_features % 8 == 0 and layer.linear1.out_features <= 2048:
             # update path: out_proj + add + LayerNorm, linear1 + ReLU + dropout, linear2 + add + LayerNorm as three ops
@@ -160,14 +175,17 @@ class TransformerEncoder(nn.Module):
         return (boards.dtype == torch.uint8 and boards.dim() == 2 and boards.shape[1] == 16 and self.d_model == 256
                 and tuple(emb_weight.shape) == (256, 31) and _train_bf16(boards, emb_weight))
 
-    def forward_boards(self, boards: torch.Tensor, emb_weight: torch.Tensor, reduction: str = "mean") -> torch.Tensor:
-        """Packed boards u8 [B, 16] -> [B, d_model] (embedding, positions, CLS and the encoder layers)."""
+    def forward_boards(self, boards: torch.Tensor, emb_weight: torch.Tensor, reduction: str = "mean", tail_heads=None):
+        """Packed boards u8 [B, 16] -> [B, d_model] (embedding, positions, CLS and the encoder layers); with ``tail_heads`` (see
+        ``encode``) possibly the heads' outputs instead."""
         pe = self.positional_encoding.flat_table().float().contiguous()
         p = self.positional_encoding.dropout.p if self.training else 0.0
-        return self.encode(_EmbedBoards.apply(boards, emb_weight, pe, self.cls_token, p), reduction)
+        return self.encode(_EmbedBoards.apply(boards, emb_weight, pe, self.cls_token, p), reduction, tail_heads)
 
-    def encode(self, x: torch.Tensor, reduction: str = "mean") -> torch.Tensor:
-        """[B, 17, d_model] tokens (CLS first, positions added) through the encoder layers -> [B, d_model]."""
+    def encode(self, x: torch.Tensor, reduction: str = "mean", tail_heads=None):
+        """[B, 17, d_model] tokens (CLS first, positions added) through the encoder layers -> [B, d_model].
+        ``tail_heads(o, x_cls, params, dense, transposed, eps, p) -> (logits, values)``: offered by an agent whose heads can run
+        inside the fused CLS tail; when the update path takes it, the return value is that tuple instead of the features."""
         if reduction not in ["mean", "cls"]:
             raise ValueError(f"reduction must be 'mean' or 'cls', got {reduction}")
         layers = self.encoder.layers
@@ -181,7 +199,10 @@ class TransformerEncoder(nn.Module):
             x, h = self._layer(layer, x, h, layers[i + 1].norm1 if i < last else None,
                                cls_only=(reduction == "cls" and i == last), sh=sh[i],
                                cls_link_out=cls_link if i == last - 1 else None,
-                               cls_link_in=cls_link if i == last else None)
+                               cls_link_in=cls_link if i == last else None,
+                               tail_heads=tail_heads if (i == last and self.encoder.norm is None) else None)
+            if isinstance(x, tuple):  # (logits, values) from the fused CLS tail
+                return x
         if self.encoder.norm is not None:
             x = self.encoder.norm(x)
         if reduction == "cls":

@@ -382,6 +382,71 @@ int g2048_opt_step(const g2048_opt_chunk *chunks, int n_chunks, const float *gra
                    int32_t *growth_tracker, float growth, float backoff, int growth_interval, float *workspace,
                    float *info, void *stream);
 
+/* ---- policy network (update): the 2048-row tail as two kernels -------------------------------------------------- */
+
+/* Everything after the last encoder layer's attention works on ONE row per board (the "cls" reduction reads only the CLS row
+ * of the last layer): out_proj + dropout + residual + LayerNorm(norm2), linear1 + ReLU + dropout, linear2 + dropout +
+ * residual, then the actor head (256 -> 512 -> 512 -> 4) and the critic head (256 -> 512 -> 512 -> 1)
+ * (reference: nn.TransformerEncoderLayer(norm_first=True), src/ppo/transformer_encoder.py:138-148 and :150-190 for the CLS
+ * read-out; the heads of src/ppo/ppo_agent.py:62-92, evaluated by evaluate_actions :159-191).  d_model 256, feed-forward
+ * 1024, head width 512.  g2048_cls_tail_fwd runs that chain for M rows in one launch, g2048_cls_tail_bwd its backward, and
+ * g2048_dweight_t all weight / bias gradients from the transposed operands the two leave behind.
+ * Weights: bf16 copies in nn.Linear's [out][in] layout (16-byte aligned), biases and LayerNorm parameters f32. */
+typedef struct {
+    const void *wo, *w1, *w2;           /* out_proj [256][256], linear1 [1024][256], linear2 [256][1024] */
+    const void *a1, *a2, *a3;           /* actor  [512][256], [512][512], [4][512] (no bias) */
+    const void *c1, *c2, *c3;           /* critic [512][256], [512][512], [1][512] (no bias) */
+    const float *bo, *b1, *b2, *ab1, *ab2, *cb1, *cb2;
+    const float *ln_g, *ln_b;           /* norm2 */
+} g2048_tail_weights;
+/* the backward multiplies with the TRANSPOSED weights ([in][out], bf16; g2048_opt_step keeps such shadows current) */
+typedef struct {
+    const void *woT, *w1T, *w2T;        /* [256][256], [256][1024], [1024][256] */
+    const void *a1T, *a2T, *a3;         /* [256][512], [512][512]; a3 as it is, [4][512] */
+    const void *c1T, *c2T, *c3;         /* [256][512], [512][512]; c3 as it is, [1][512] */
+    const float *ln_g;
+} g2048_tail_weights_t;
+/* What the forward leaves for the backward and for the weight gradients.  ld = leading dimension (elements) of every
+ * transposed buffer, a multiple of 32 and >= 32 * ceil(M / 32); columns M..ld-1 are written as zero.
+ * masks: u16 [ceil(M/32)][G2048_TAIL_MASK_TILES][64], one bit per element of an MFMA accumulator tile (private layout). */
+#define G2048_TAIL_MASK_TILES 96
+typedef struct {
+    float *x_mid, *mean, *rstd;         /* f32 [M][256] residual after the attention block; LayerNorm statistics [M] */
+    void *masks;
+    void *oT, *h2T, *uT, *featsT;       /* bf16 [256][ld], [256][ld], [1024][ld], [256][ld]: inputs of out_proj, linear1, linear2, heads */
+    void *a1T, *a2T, *c1T, *c2T;        /* bf16 [512][ld] each: hidden activations of the heads */
+    int64_t ld;
+} g2048_tail_saved;
+/* dY^T of every Linear (bf16, [out][ld]; dlT / dvT have 32 rows of which 4 / 1 are written: allocate them zero-filled) and
+ * the LayerNorm gradient partials f32 [ceil(M/32)][2][256] (dgamma | dbeta per workgroup, for g2048_reduce_jobs). */
+typedef struct {
+    void *daoT, *dzT, *df2T;            /* out_proj [256][ld], linear1 [1024][ld], linear2 [256][ld] */
+    void *da1T, *da2T, *dlT;            /* actor [512][ld], [512][ld], [32][ld] */
+    void *dc1T, *dc2T, *dvT;            /* critic [512][ld], [512][ld], [32][ld] */
+    float *ln_partial;
+} g2048_tail_grads;
+/* o: bf16 [M][256] attention output of the CLS rows; x_cls: f32 rows of 256 with element stride x_row_stride (the CLS rows
+ * of the residual stream, read in place); logits f32 [M][4], values f32 [M].  Dropout as everywhere in the update: the mask
+ * is a function of (seed, *seed_state, site, element); pass the same triple to the backward. */
+int g2048_cls_tail_fwd(const void *o, const float *x_cls, int64_t x_row_stride, const g2048_tail_weights *W,
+                       const g2048_tail_saved *S, float *logits, float *values, int64_t M, float eps, float p_drop, uint64_t seed,
+                       const uint64_t *seed_state, void *stream);
+/* dlogits f32 [M][4], dvalues f32 [M] -> d_o bf16 [M][256] (gradient of the attention output), dx_cls f32 [M][256]
+ * (gradient of the residual CLS rows), G (see above). */
+int g2048_cls_tail_bwd(const float *dlogits, const float *dvalues, const g2048_tail_weights_t *WT, const g2048_tail_saved *S,
+                       const g2048_tail_grads *G, void *d_o, float *dx_cls, int64_t M, float p_drop, uint64_t seed,
+                       const uint64_t *seed_state, void *stream);
+
+/* Weight gradients from transposed operands, all jobs in one launch: for job j,
+ * dw[s][n][k] = sum over the s-th of `slices` equal pieces of the row axis of dyT[n][m] * xT[k][m]   (f32 [slices][N][K]),
+ * db[s][n]    = the same sum of dyT[n][m]                                                        (f32 [slices][N], or NULL);
+ * dyT bf16 [N][ld], xT bf16 [K][ld], N and K multiples of 32, m (rows used, <= ld) a multiple of 16 * slices.  The slices are
+ * summed by g2048_reduce_jobs.  Replaces dY^T X (torch: `dy.t() @ x`) and the bias column sums in the backward of every
+ * nn.Linear of the tail (reference: loss.backward() at src/ppo/ppo_trainer.py:410-414).  jobs: host array, read during the call. */
+#define G2048_DW_MAX_JOBS 16
+typedef struct { const void *dyT; const void *xT; float *dw; float *db; int32_t N, K; } g2048_dw_job;
+int g2048_dweight_t(const g2048_dw_job *jobs, int n_jobs, int64_t ld, int64_t m, int slices, void *stream);
+
 /* Row i of the minibatch = sample idx[i] (int64, clamped to [0, N)) of the device-resident rollout buffer: boards
  * u8 [N][16], actions u8 [N], masks u8 [N], logp / adv / ret f32 [N] -> the o_* arrays of M rows.  One launch for what
  * the reference's DataLoader collation does per field (PPODataset.__getitem__, src/ppo/data_loader.py). */
