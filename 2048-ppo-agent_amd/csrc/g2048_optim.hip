@@ -98,13 +98,37 @@ __device__ __forceinline__ uint16_t to_bf16(float f) {
     const __bf16 b = (__bf16)f;
     return *reinterpret_cast<const uint16_t *>(&b);
 }
-// `tiled`: the transposed copy of this chunk goes through LDS (see k_opt_adamw) and is not written here
+// offset of element (row, col) of a [rows][cols] matrix in the fragment-packed layout (include/g2048.h)
+__device__ __forceinline__ int64_t packed_off(int64_t row, int64_t col, int64_t cols) {
+    return ((((row >> 5) * (cols >> 4) + (col >> 4)) * 2 + ((col >> 3) & 1)) * 32 + (row & 31)) * 8 + (col & 7);
+}
+// `tiled`: the transposed copies of this chunk go through LDS (see k_opt_adamw) and is not written here
 __device__ __forceinline__ void refresh_shadow(const g2048_opt_chunk &c, int i, float a, float b, float cc, float d, int n, bool tiled,
                                                uint16_t *stage) {
     const float vals[4] = {a, b, cc, d};
     const int64_t e = (int64_t)c.e0 + i;
     if (tiled) {
         for (int q = 0; q < n; ++q) stage[i + q] = to_bf16(vals[q]);
+    }
+    if (c.shadow_p) {  // fragment-packed copy: 4 consecutive columns of one row are 8 contiguous bytes there as well
+        uint16_t *s = reinterpret_cast<uint16_t *>(c.shadow_p);
+        const int64_t row = e / c.cols, col = e - row * c.cols;
+        if (n == 4 && !(col & 3)) {
+            *reinterpret_cast<uint2 *>(s + packed_off(row, col, c.cols)) =
+                make_uint2((uint32_t)to_bf16(a) | ((uint32_t)to_bf16(b) << 16), (uint32_t)to_bf16(cc) | ((uint32_t)to_bf16(d) << 16));
+        } else {
+            for (int q = 0; q < n; ++q) {
+                const int64_t eq = e + q, rq = eq / c.cols;
+                s[packed_off(rq, eq - rq * c.cols, c.cols)] = to_bf16(vals[q]);
+            }
+        }
+    }
+    if (c.shadow_tp && !tiled) {
+        uint16_t *t = reinterpret_cast<uint16_t *>(c.shadow_tp);
+        for (int q = 0; q < n; ++q) {
+            const int64_t eq = e + q, rq = eq / c.cols;
+            t[packed_off(eq - rq * c.cols, rq, c.rows)] = to_bf16(vals[q]);
+        }
     }
     if (c.shadow) {
         uint16_t *s = reinterpret_cast<uint16_t *>(c.shadow) + e;
@@ -141,10 +165,11 @@ k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const floa
     // are staged in LDS and written as one 2R-byte run per column (R consecutive rows of the [cols][rows] copy) instead of one
     // scattered 2-byte store per element (round 2: 22 -> 30 us for the step with one transposed weight per layer; round 3 adds
     // the transposed copies the fused CLS tail's backward multiplies with)
-    const int rows_in_chunk = (c.shadow_t && c.cols > 0) ? OPT_CHUNK / c.cols : 0;
-    const bool tiled = c.shadow_t && c.n == OPT_CHUNK && c.cols > 0 && OPT_CHUNK % c.cols == 0 && c.e0 % c.cols == 0 &&
+    const bool any_t = c.shadow_t || c.shadow_tp;
+    const int rows_in_chunk = (any_t && c.cols > 0) ? OPT_CHUNK / c.cols : 0;
+    const bool tiled = any_t && c.n == OPT_CHUNK && c.cols > 0 && OPT_CHUNK % c.cols == 0 && c.e0 % c.cols == 0 &&
                        (rows_in_chunk == 2 || rows_in_chunk == 4 || rows_in_chunk == 8) && c.rows % rows_in_chunk == 0 &&
-                       !((uintptr_t)c.shadow_t & 15);
+                       !(((uintptr_t)c.shadow_t | (uintptr_t)c.shadow_tp) & 15);
     if (threadIdx.x == 0) {
         const float sc = scale ? *scale : 1.f;
         const float inv_scale = (float)(1.0 / (double)sc);  // scaler.unscale_: grads *= scale.double().reciprocal().float()
@@ -178,32 +203,40 @@ k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const floa
                 *reinterpret_cast<float4 *>(p + i) = pv;
                 *reinterpret_cast<float4 *>(m + i) = mv;
                 *reinterpret_cast<float4 *>(v + i) = vv;
-                if (c.shadow || c.shadow_t) refresh_shadow(c, i, pv.x, pv.y, pv.z, pv.w, 4, tiled, stage);
+                if (c.shadow || c.shadow_p || any_t) refresh_shadow(c, i, pv.x, pv.y, pv.z, pv.w, 4, tiled, stage);
             } else {
                 for (int k = i; k < c.n; ++k) {
                     float pk = p[k], mk = m[k], vk = v[k];
                     adamw1(pk, (g[k] * inv_scale) * clip, mk, vk, lr_wd, w1, b2, w2, step_size, inv_bc2_sqrt, eps);
                     p[k] = pk; m[k] = mk; v[k] = vk;
-                    if (c.shadow || c.shadow_t) refresh_shadow(c, k, pk, 0.f, 0.f, 0.f, 1, tiled, stage);
+                    if (c.shadow || c.shadow_p || any_t) refresh_shadow(c, k, pk, 0.f, 0.f, 0.f, 1, tiled, stage);
                 }
             }
         }
         if (tiled) {  // (uniform per workgroup)
             __syncthreads();
             const int R = rows_in_chunk, r0 = c.e0 / c.cols;
-            uint16_t *t = reinterpret_cast<uint16_t *>(c.shadow_t);
+            // the run of R consecutive rows of one column: 2R contiguous bytes of the [cols][rows] copy, and (R <= 8, r0 % R == 0)
+            // of its fragment-packed form too
             for (int col = threadIdx.x; col < c.cols; col += OPT_THREADS) {
-                uint16_t *dst = t + (int64_t)col * c.rows + r0;
                 const uint16_t *src = stage + col;
                 const int cs = c.cols;
-                if (R == 8)
-                    *reinterpret_cast<uint4 *>(dst) = make_uint4(src[0] | ((uint32_t)src[cs] << 16), src[2 * cs] | ((uint32_t)src[3 * cs] << 16),
-                                                                 src[4 * cs] | ((uint32_t)src[5 * cs] << 16),
-                                                                 src[6 * cs] | ((uint32_t)src[7 * cs] << 16));
-                else if (R == 4)
-                    *reinterpret_cast<uint2 *>(dst) = make_uint2(src[0] | ((uint32_t)src[cs] << 16), src[2 * cs] | ((uint32_t)src[3 * cs] << 16));
-                else
-                    *reinterpret_cast<uint32_t *>(dst) = src[0] | ((uint32_t)src[cs] << 16);
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                if (R == 8) {
+                    for (int q = 0; q < 4; ++q) w[q] = src[2 * q * cs] | ((uint32_t)src[(2 * q + 1) * cs] << 16);
+                } else if (R == 4) {
+                    for (int q = 0; q < 2; ++q) w[q] = src[2 * q * cs] | ((uint32_t)src[(2 * q + 1) * cs] << 16);
+                } else {
+                    w[0] = src[0] | ((uint32_t)src[cs] << 16);
+                }
+                for (int which = 0; which < 2; ++which) {
+                    uint16_t *base = reinterpret_cast<uint16_t *>(which ? c.shadow_tp : c.shadow_t);
+                    if (!base) continue;
+                    uint16_t *dst = base + (which ? packed_off(col, r0, c.rows) : (int64_t)col * c.rows + r0);
+                    if (R == 8) *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+                    else if (R == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(w[0], w[1]);
+                    else *reinterpret_cast<uint32_t *>(dst) = w[0];
+                }
             }
         }
     }

@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/g2048.h"
 
 namespace {
@@ -114,15 +116,24 @@ __device__ __forceinline__ void put4(char *buf, int stride, int r, int col, cons
     for (int q = 0; q < 4; ++q) pk[q] = (__bf16)v[q];
     *reinterpret_cast<bf16x4 *>(buf + r * stride + 2 * col) = pk;
 }
-// dstT[(f0 + f) * ld + m0 + row] = buf[row][f] for f < nfeat, row < 32: the transposed copy the weight-gradient kernel reads
-// (16-byte stores of 8 rows each).  Call between two barriers; nfeat a multiple of 64.
-__device__ __forceinline__ void lds_to_T(const char *buf, int stride, int nfeat, __bf16 *__restrict__ dstT, int64_t ld, int64_t m0,
-                                         int tid) {
+// Fragment-packed layout of a bf16 matrix X[rows][cols] (rows % 32 == 0, cols % 16 == 0), the order in which a wavefront reads
+// it as an MFMA operand: for every 32-row tile and every 16-column k-step, 64 lanes x 16 bytes = 1 KB contiguous,
+//   offset(row, col) = ((((row / 32) * (cols / 16) + col / 16) * 2 + (col / 8) % 2) * 32 + row % 32) * 8 + col % 8.
+// Row-major operands make every lane of a fragment load touch a different cache line (lane = row): 64 requests of 16 bytes per
+// instruction, measured ~8 B/clk per CU; packed, one instruction is one contiguous KB.
+__device__ __forceinline__ int64_t packed_off(int row, int64_t col, int64_t cols) {
+    return ((((int64_t)(row >> 5) * (cols >> 4) + (col >> 4)) * 2 + ((col >> 3) & 1)) * 32 + (row & 31)) * 8 + (col & 7);
+}
+// the transposed copy the weight-gradient kernel reads, X^T[f0 + f][m0 + row] = buf[row][f] for f < nfeat, row < 32, stored
+// fragment-packed with leading dimension (columns) ld: 16-byte stores of 8 rows each, consecutive threads = consecutive slots.
+// Call between two barriers; nfeat and f0 multiples of 32.
+__device__ __forceinline__ void lds_to_T(const char *buf, int stride, int nfeat, __bf16 *__restrict__ dstT, int f0, int64_t ld,
+                                         int64_t m0, int tid) {
     for (int e = tid; e < nfeat * 4; e += THREADS) {
         const int f = e % nfeat, g = e / nfeat;
         bf16x8 v;
         for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const __bf16 *>(buf + (8 * g + j) * stride + 2 * f);
-        *reinterpret_cast<bf16x8 *>(dstT + (int64_t)f * ld + m0 + 8 * g) = v;
+        *reinterpret_cast<bf16x8 *>(dstT + packed_off(f0 + f, m0 + 8 * g, ld)) = v;
     }
 }
 
@@ -137,76 +148,64 @@ struct TailLds {
 static_assert(sizeof(TailLds) <= 160 * 1024, "LDS budget");
 
 // ---------------------------------------------------------------------------------------------------------------------
+// weight stream: every wave walks a fixed list of UNITS, one unit = 16 operand fragments (16 KB per wave) = one 32-row
+// weight tile over 256 inputs, or two 32-row tiles over 128 inputs.  Unit i is fetched into ring slot i % RING while unit
+// i - DIST is being multiplied, across phase boundaries and barriers (weights depend on nothing): without this every tile
+// exposed one L2 round trip (~2 us) before its 0.2 us of MFMAs and the kernels took 158 / 133 us instead of ~30.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int RING = 3, DIST = 2, N_UNITS = 42;  // RING = DIST + 1: the slot of unit i + DIST was last read by unit i - 1
+
+template <int I, int N, class Fn>
+__device__ __forceinline__ void static_for(Fn &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// LDS-only barrier: __syncthreads() would also wait for the weight fetches that are meant to stay in flight (vmcnt(0))
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    sched_fence();
+}
+struct Ring {
+    bf16x8 a[RING][16];
+};
+// fragments 0..7 at p + 512 ks, fragments 8..15 at p + off2 + 512 ks (elements; p = this lane's 16 bytes of the first fragment of a
+// fragment-packed weight: one contiguous KB per wave-instruction)
+template <int SLOT>
+__device__ __forceinline__ void fetch_unit(Ring &R, const __bf16 *p, int64_t off2) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) R.a[SLOT][ks] = *reinterpret_cast<const bf16x8 *>(p + 512 * ks);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) R.a[SLOT][8 + ks] = *reinterpret_cast<const bf16x8 *>(p + off2 + 512 * ks);
+}
+template <int SLOT>
+__device__ __forceinline__ f32x16 mm16(const Ring &R, const bf16x8 *xf, f32x16 acc) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = mfma(R.a[SLOT][ks], xf[ks], acc);
+    return acc;
+}
+template <int SLOT, int HALF>
+__device__ __forceinline__ f32x16 mm8(const Ring &R, const bf16x8 *xf, f32x16 acc) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) acc = mfma(R.a[SLOT][8 * HALF + ks], xf[ks], acc);
+    return acc;
+}
+// per-lane address of a unit's first fragment in a fragment-packed [rows][cols] weight: row tile row0 / 32, k-step k0 / 16
+__device__ __forceinline__ const __bf16 *unit_ptr(const void *W, int cols, int row0, int k0, int lane) {
+    return (const __bf16 *)W + ((size_t)(row0 >> 5) * (cols >> 4) + (k0 >> 4)) * 512 + lane * 8;
+}
+constexpr int64_t NEXT_8_STEPS = 8 * 512;  // off2 of a unit = one row tile over 256 columns
+__device__ __forceinline__ int64_t next_row_tile(int cols) { return (int64_t)(cols >> 4) * 512; }  // off2 of a unit = two row tiles over 128 columns
+
+// ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
-// Linear(256 -> 512) + ReLU, Linear(512 -> 512) + ReLU, Linear(512 -> n_out, no bias) on the bf16 features in L.xa
-template <int N_OUT>
-__device__ __forceinline__ void head_fwd(TailLds &L, const __bf16 *w1, const float *b1, const __bf16 *w2, const float *b2,
-                                         const __bf16 *w3, int mt1, int mt2, uint16_t *masks_wg, __bf16 *h1T, __bf16 *h2T, int64_t ld,
-                                         int64_t m0, bool valid, float *out, int64_t M, int tid, int lane, int r, int h, int w) {
-    {
-        bf16x8 ff[16];
-        load_frags<16>(L.xa, S256, 0, ff, r, h);
-        for (int t = 0; t < 4; ++t) {
-            const int mt = 4 * w + t;
-            f32x16 acc = tile_gemm<16>(w1, D, 32 * mt, 0, ff, bias_tile(b1, 32 * mt, h), r, h);
-            uint32_t bits = 0;
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-                for (int q = 0; q < 4; ++q) {
-                    v[q] = valid ? fmaxf(acc[4 * g + q], 0.f) : 0.f;
-                    bits |= (uint32_t)((float)(__bf16)v[q] != 0.f) << (4 * g + q);
-                }
-                put4(L.xb, S512, r, 32 * mt + 8 * g + 4 * h, v);
-            }
-            masks_wg[(mt1 + mt) * 64 + lane] = (uint16_t)bits;
-        }
-    }
-    __syncthreads();
-    lds_to_T(L.xb, S512, HID, h1T, ld, m0, tid);
-    {
-        bf16x8 af[32];
-        load_frags<32>(L.xb, S512, 0, af, r, h);
-        for (int t = 0; t < 4; ++t) {
-            const int mt = 4 * w + t;
-            f32x16 acc = tile_gemm<16>(w2, HID, 32 * mt, 0, af, bias_tile(b2, 32 * mt, h), r, h);
-            acc = tile_gemm<16>(w2, HID, 32 * mt, 256, af + 16, acc, r, h);
-            uint32_t bits = 0;
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-                for (int q = 0; q < 4; ++q) {
-                    v[q] = valid ? fmaxf(acc[4 * g + q], 0.f) : 0.f;
-                    bits |= (uint32_t)((float)(__bf16)v[q] != 0.f) << (4 * g + q);
-                }
-                put4(L.xc, S512, r, 32 * mt + 8 * g + 4 * h, v);
-            }
-            masks_wg[(mt2 + mt) * 64 + lane] = (uint16_t)bits;
-        }
-    }
-    __syncthreads();
-    lds_to_T(L.xc, S512, HID, h2T, ld, m0, tid);
-    {   // the output layer (4 logits / 1 value) on the vector ALU: 8 threads per row, 64 inputs each
-        const int row = tid >> 3, part = tid & 7;
-        float s[N_OUT];
-        for (int o = 0; o < N_OUT; ++o) s[o] = 0.f;
-        for (int c = 0; c < 8; ++c) {
-            const bf16x8 x = *reinterpret_cast<const bf16x8 *>(L.xc + row * S512 + 2 * (64 * part + 8 * c));
-            for (int o = 0; o < N_OUT; ++o) {
-                const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(w3 + o * HID + 64 * part + 8 * c);
-                for (int j = 0; j < 8; ++j) s[o] = __builtin_fmaf((float)x[j], (float)wv[j], s[o]);
-            }
-        }
-        for (int o = 0; o < N_OUT; ++o) {
-            s[o] += __shfl_xor(s[o], 1);
-            s[o] += __shfl_xor(s[o], 2);
-            s[o] += __shfl_xor(s[o], 4);
-        }
-        if (part == 0 && m0 + row < M)
-            for (int o = 0; o < N_OUT; ++o) out[(m0 + row) * N_OUT + o] = s[o];
-    }
-    __syncthreads();  // xb / xc are free again
-}
-
+// units of wave w: 0-1 out_proj tiles 2w, 2w+1 | 2+2c linear1 tile 4c+w, 3+2c linear2 tiles 2w, 2w+1 over chunk c (c < 8) |
+// 18-21 actor L1 tiles 4w+t, 22-29 actor L2 tile 4w+t halves 0/1 | 30-41 the same for the critic
 __global__ void __launch_bounds__(THREADS, 1)
 k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_t x_rs, g2048_tail_weights W, g2048_tail_saved S,
            float *__restrict__ logits, float *__restrict__ values, int64_t M, float eps, float p_drop, uint64_t seed,
@@ -220,7 +219,29 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
     const Drop drop = make_drop(seed, seed_state, p_drop);
     float *const xm = reinterpret_cast<float *>(L.xc);
     uint16_t *const masks_wg = reinterpret_cast<uint16_t *>(S.masks) + (int64_t)blockIdx.x * N_MASK_TILES * 64;
-    const __bf16 *wo = (const __bf16 *)W.wo, *w1 = (const __bf16 *)W.w1, *w2 = (const __bf16 *)W.w2;
+
+    Ring R;
+    auto issue = [&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < N_UNITS) {
+            constexpr int slot = i % RING;
+            if constexpr (i < 2) {
+                fetch_unit<slot>(R, unit_ptr(W.wo, D, 32 * (2 * w + i), 0, lane), NEXT_8_STEPS);
+            } else if constexpr (i < 18) {
+                constexpr int c = (i - 2) / 2;
+                if constexpr ((i - 2) % 2 == 0) fetch_unit<slot>(R, unit_ptr(W.w1, D, 32 * (4 * c + w), 0, lane), NEXT_8_STEPS);
+                else fetch_unit<slot>(R, unit_ptr(W.w2, FF, 32 * (2 * w), FC * c, lane), next_row_tile(FF));
+            } else {
+                constexpr int j = (i - 18) % 12;
+                const void *l1 = i < 30 ? W.a1 : W.c1, *l2 = i < 30 ? W.a2 : W.c2;
+                if constexpr (j < 4) fetch_unit<slot>(R, unit_ptr(l1, D, 32 * (4 * w + j), 0, lane), NEXT_8_STEPS);
+                else fetch_unit<slot>(R, unit_ptr(l2, HID, 32 * (4 * w + (j - 4) / 2), 256 * ((j - 4) % 2), lane), NEXT_8_STEPS);
+            }
+        }
+        sched_fence();
+    };
+    issue(std::integral_constant<int, 0>{});
+    issue(std::integral_constant<int, 1>{});
 
     // ---- the tile's inputs: attention output rows -> xa (bf16), residual CLS rows -> xm (f32); rows past M are zero
     for (int p = 0; p < 4; ++p) {
@@ -235,17 +256,19 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
         if (m0 + row < M) v = *reinterpret_cast<const float4 *>(x_cls + (m0 + row) * x_rs + 4 * c4);
         *reinterpret_cast<float4 *>(xm + row * XM_S + 4 * c4) = v;
     }
-    __syncthreads();
-    lds_to_T(L.xa, S256, D, (__bf16 *)S.oT, ld, m0, tid);
+    lds_barrier();
+    lds_to_T(L.xa, S256, D, (__bf16 *)S.oT, 0, ld, m0, tid);
 
     // ---- out_proj, dropout, residual add: x_mid = x + dropout(bf16(Wo o + bo))
     {
         bf16x8 xf[16];
         load_frags<16>(L.xa, S256, 0, xf, r, h);
         const Drop d1 = drop.site(1);
-        for (int j = 0; j < 2; ++j) {
+        static_for<0, 2>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
             const int mt = 2 * w + j;
-            const f32x16 acc = tile_gemm<16>(wo, D, 32 * mt, 0, xf, bias_tile(W.bo, 32 * mt, h), r, h);
+            issue(std::integral_constant<int, j + DIST>{});
+            const f32x16 acc = mm16<j % RING>(R, xf, bias_tile(W.bo, 32 * mt, h));
             for (int g = 0; g < 4; ++g) {
                 const int f0 = 32 * mt + 8 * g + 4 * h;
                 f32x4 x = *reinterpret_cast<const f32x4 *>(xm + r * XM_S + f0);
@@ -253,9 +276,9 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
                     x[q] += d1.apply((float)(__bf16)acc[4 * g + q], (uint64_t)(m0 + r) * D + f0 + q);
                 *reinterpret_cast<f32x4 *>(xm + r * XM_S + f0) = x;
             }
-        }
+        });
     }
-    __syncthreads();
+    lds_barrier();
     // ---- LayerNorm of the 32 rows, one wavefront per row (the arithmetic of k_add_ln_fwd): h2 -> xb, x_mid + statistics saved
     {
         const float4 gm = reinterpret_cast<const float4 *>(W.ln_g)[lane], bt = reinterpret_cast<const float4 *>(W.ln_b)[lane];
@@ -278,8 +301,8 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
             }
         }
     }
-    __syncthreads();
-    lds_to_T(L.xb, S256, D, (__bf16 *)S.h2T, ld, m0, tid);
+    lds_barrier();
+    lds_to_T(L.xb, S256, D, (__bf16 *)S.h2T, 0, ld, m0, tid);
 
     // ---- feed-forward: u = dropout(relu(W1 h2 + b1)) in chunks of 128 hidden units, f = W2 u + b2 accumulated per chunk
     {
@@ -288,11 +311,12 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
         const Drop d2 = drop.site(2), d3 = drop.site(3);
         f32x16 acc2[2];
         for (int j = 0; j < 2; ++j) acc2[j] = bias_tile(W.b2, 32 * (2 * w + j), h);
-#pragma nounroll
-        for (int c = 0; c < FF / FC; ++c) {
+        static_for<0, FF / FC>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value, u1 = 2 + 2 * c, u2 = 3 + 2 * c;
             const int ht = 4 * c + w;  // hidden tile of this wave
             char *ub = L.u[c & 1];
-            const f32x16 z = tile_gemm<16>(w1, D, 32 * ht, 0, xf, bias_tile(W.b1, 32 * ht, h), r, h);
+            issue(std::integral_constant<int, u1 + DIST>{});
+            const f32x16 z = mm16<u1 % RING>(R, xf, bias_tile(W.b1, 32 * ht, h));
             uint32_t bits = 0;
             for (int g = 0; g < 4; ++g) {
                 float v[4];
@@ -304,14 +328,16 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
                 put4(ub, S128, r, 32 * w + 8 * g + 4 * h, v);
             }
             masks_wg[(MT_FFN + ht) * 64 + lane] = (uint16_t)bits;
-            __syncthreads();  // chunk c of every wave visible (the other buffer is still being read by nobody: see below)
-            lds_to_T(ub, S128, FC, (__bf16 *)S.uT + (int64_t)(FC * c) * ld, ld, m0, tid);
+            lds_barrier();  // chunk c of every wave visible
+            lds_to_T(ub, S128, FC, (__bf16 *)S.uT, FC * c, ld, m0, tid);
             bf16x8 uf[8];
             load_frags<8>(ub, S128, 0, uf, r, h);
-            for (int j = 0; j < 2; ++j) acc2[j] = tile_gemm<8>(w2, FF, 32 * (2 * w + j), FC * c, uf, acc2[j], r, h);
+            issue(std::integral_constant<int, u2 + DIST>{});
+            acc2[0] = mm8<u2 % RING, 0>(R, uf, acc2[0]);
+            acc2[1] = mm8<u2 % RING, 1>(R, uf, acc2[1]);
             // a wave reaches the writes of chunk c + 2 (same buffer) only after the barrier of chunk c + 1, which every wave
             // passes after these reads
-        }
+        });
         // ---- features = bf16(x_mid + dropout(bf16(f))) -> xa
         for (int j = 0; j < 2; ++j) {
             const int mt = 2 * w + j;
@@ -325,77 +351,93 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
             }
         }
     }
-    __syncthreads();
-    lds_to_T(L.xa, S256, D, (__bf16 *)S.featsT, ld, m0, tid);
-    __syncthreads();  // xc (the f32 residual tile) is dead from here on: the heads write bf16 rows into it
+    lds_barrier();
+    lds_to_T(L.xa, S256, D, (__bf16 *)S.featsT, 0, ld, m0, tid);
+    lds_barrier();  // xc (the f32 residual tile) is dead from here on: the heads write bf16 rows into it
 
-    head_fwd<4>(L, (const __bf16 *)W.a1, W.ab1, (const __bf16 *)W.a2, W.ab2, (const __bf16 *)W.a3, MT_A1, MT_A2, masks_wg,
-                (__bf16 *)S.a1T, (__bf16 *)S.a2T, ld, m0, valid, logits, M, tid, lane, r, h, w);
-    head_fwd<1>(L, (const __bf16 *)W.c1, W.cb1, (const __bf16 *)W.c2, W.cb2, (const __bf16 *)W.c3, MT_C1, MT_C2, masks_wg,
-                (__bf16 *)S.c1T, (__bf16 *)S.c2T, ld, m0, valid, values, M, tid, lane, r, h, w);
+    // ---- heads: Linear(256 -> 512) + ReLU, Linear(512 -> 512) + ReLU, Linear(512 -> n_out, no bias) on the features in xa
+    auto head = [&](auto u0c, auto nout_c, const float *b1, const float *b2, const __bf16 *w3, int mt1, int mt2, __bf16 *h1T, __bf16 *h2T,
+                    float *out) __attribute__((always_inline)) {
+        constexpr int U0 = decltype(u0c)::value, N_OUT = decltype(nout_c)::value;
+        {
+            bf16x8 ff[16];
+            load_frags<16>(L.xa, S256, 0, ff, r, h);
+            static_for<0, 4>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value, u = U0 + t;
+                const int mt = 4 * w + t;
+                issue(std::integral_constant<int, u + DIST>{});
+                const f32x16 acc = mm16<u % RING>(R, ff, bias_tile(b1, 32 * mt, h));
+                uint32_t bits = 0;
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+                    for (int q = 0; q < 4; ++q) {
+                        v[q] = valid ? fmaxf(acc[4 * g + q], 0.f) : 0.f;
+                        bits |= (uint32_t)((float)(__bf16)v[q] != 0.f) << (4 * g + q);
+                    }
+                    put4(L.xb, S512, r, 32 * mt + 8 * g + 4 * h, v);
+                }
+                masks_wg[(mt1 + mt) * 64 + lane] = (uint16_t)bits;
+            });
+        }
+        lds_barrier();
+        lds_to_T(L.xb, S512, HID, h1T, 0, ld, m0, tid);
+        {
+            static_for<0, 4>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value, u = U0 + 4 + 2 * t;
+                const int mt = 4 * w + t;
+                bf16x8 af[16];  // (re-read per tile: 128 registers for all 32 fragments would push the weight ring into scratch)
+                issue(std::integral_constant<int, u + DIST>{});
+                load_frags<16>(L.xb, S512, 0, af, r, h);
+                f32x16 acc = mm16<u % RING>(R, af, bias_tile(b2, 32 * mt, h));
+                issue(std::integral_constant<int, u + 1 + DIST>{});
+                load_frags<16>(L.xb, S512, 256, af, r, h);
+                acc = mm16<(u + 1) % RING>(R, af, acc);
+                uint32_t bits = 0;
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+                    for (int q = 0; q < 4; ++q) {
+                        v[q] = valid ? fmaxf(acc[4 * g + q], 0.f) : 0.f;
+                        bits |= (uint32_t)((float)(__bf16)v[q] != 0.f) << (4 * g + q);
+                    }
+                    put4(L.xc, S512, r, 32 * mt + 8 * g + 4 * h, v);
+                }
+                masks_wg[(mt2 + mt) * 64 + lane] = (uint16_t)bits;
+            });
+        }
+        lds_barrier();
+        lds_to_T(L.xc, S512, HID, h2T, 0, ld, m0, tid);
+        {   // the output layer (4 logits / 1 value) on the vector ALU: 8 threads per row, 64 inputs each
+            const int row = tid >> 3, part = tid & 7;
+            float s[N_OUT];
+            for (int oo = 0; oo < N_OUT; ++oo) s[oo] = 0.f;
+            for (int c = 0; c < 8; ++c) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8 *>(L.xc + row * S512 + 2 * (64 * part + 8 * c));
+                for (int oo = 0; oo < N_OUT; ++oo) {
+                    const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(w3 + oo * HID + 64 * part + 8 * c);
+                    for (int j = 0; j < 8; ++j) s[oo] = __builtin_fmaf((float)x[j], (float)wv[j], s[oo]);
+                }
+            }
+            for (int oo = 0; oo < N_OUT; ++oo) {
+                s[oo] += __shfl_xor(s[oo], 1);
+                s[oo] += __shfl_xor(s[oo], 2);
+                s[oo] += __shfl_xor(s[oo], 4);
+            }
+            if (part == 0 && m0 + row < M)
+                for (int oo = 0; oo < N_OUT; ++oo) out[(m0 + row) * N_OUT + oo] = s[oo];
+        }
+        lds_barrier();  // xb / xc are free again
+    };
+    head(std::integral_constant<int, 18>{}, std::integral_constant<int, 4>{}, W.ab1, W.ab2, (const __bf16 *)W.a3, MT_A1, MT_A2,
+         (__bf16 *)S.a1T, (__bf16 *)S.a2T, logits);
+    head(std::integral_constant<int, 30>{}, std::integral_constant<int, 1>{}, W.cb1, W.cb2, (const __bf16 *)W.c3, MT_C1, MT_C2,
+         (__bf16 *)S.c1T, (__bf16 *)S.c2T, values);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------------------
-// d(features) contribution of one head.  dl_col0 .. dl_col0 + N_OUT - 1: this head's columns of L.dl.
-// WT1 = W1^T [256][512], WT2 = W2^T [512][512] (transposed shadows), w3 [N_OUT][512] as it is.
-template <int N_OUT>
-__device__ __forceinline__ void head_bwd(TailLds &L, const __bf16 *wT1, const __bf16 *wT2, const __bf16 *w3, int dl_col0, int mt1, int mt2,
-                                         const uint16_t *masks_wg, __bf16 *d3T, __bf16 *d2T, __bf16 *d1T, int64_t ld, int64_t m0,
-                                         f32x16 dfeat[2], int tid, int lane, int r, int h, int w) {
-    // d a2 = (W3^T d out) where a2 > 0 -> xa; d out^T (bf16, rows N_OUT.. of the 32-row buffer stay zero) for the weight gradient
-    if (tid < 32 * N_OUT) {
-        const int o = tid / 32, row = tid % 32;
-        d3T[(int64_t)o * ld + m0 + row] = (__bf16)L.dl[row][dl_col0 + o];
-    }
-    for (int t = 0; t < 4; ++t) {
-        const int mt = 4 * w + t;
-        const uint32_t bits = masks_wg[(mt2 + mt) * 64 + lane];
-        float dlr[N_OUT];
-        for (int o = 0; o < N_OUT; ++o) dlr[o] = (float)(__bf16)L.dl[r][dl_col0 + o];
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = 32 * mt + 8 * g + 4 * h;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int o = 0; o < N_OUT; ++o) {
-                const bf16x4 wv = *reinterpret_cast<const bf16x4 *>(w3 + o * HID + f0);
-                for (int q = 0; q < 4; ++q) v[q] = __builtin_fmaf((float)wv[q], dlr[o], v[q]);
-            }
-            for (int q = 0; q < 4; ++q) v[q] = ((bits >> (4 * g + q)) & 1u) ? v[q] : 0.f;
-            put4(L.xa, S512, r, f0, v);
-        }
-    }
-    __syncthreads();
-    lds_to_T(L.xa, S512, HID, d2T, ld, m0, tid);
-    {   // d a1 = (W2^T d a2) where a1 > 0 -> xb
-        bf16x8 af[32];
-        load_frags<32>(L.xa, S512, 0, af, r, h);
-        for (int t = 0; t < 4; ++t) {
-            const int mt = 4 * w + t;
-            f32x16 acc = tile_gemm<16>(wT2, HID, 32 * mt, 0, af, zero_tile(), r, h);
-            acc = tile_gemm<16>(wT2, HID, 32 * mt, 256, af + 16, acc, r, h);
-            const uint32_t bits = masks_wg[(mt1 + mt) * 64 + lane];
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-                for (int q = 0; q < 4; ++q) v[q] = ((bits >> (4 * g + q)) & 1u) ? acc[4 * g + q] : 0.f;
-                put4(L.xb, S512, r, 32 * mt + 8 * g + 4 * h, v);
-            }
-        }
-    }
-    __syncthreads();
-    lds_to_T(L.xb, S512, HID, d1T, ld, m0, tid);
-    {   // d features += W1^T d a1
-        bf16x8 af[32];
-        load_frags<32>(L.xb, S512, 0, af, r, h);
-        for (int j = 0; j < 2; ++j) {
-            const int mt = 2 * w + j;
-            dfeat[j] = tile_gemm<16>(wT1, HID, 32 * mt, 0, af, dfeat[j], r, h);
-            dfeat[j] = tile_gemm<16>(wT1, HID, 32 * mt, 256, af + 16, dfeat[j], r, h);
-        }
-    }
-    __syncthreads();  // xa / xb are free again (every wave holds its fragments in registers)
-}
-
+// units of wave w: 0-7 actor L2^T tile 4w+t halves 0/1, 8-11 actor L1^T tile 2w+j halves 0/1 | 12-23 the same for the critic |
+// 24+2c linear2^T tile 4c+w, 25+2c linear1^T tiles 2w, 2w+1 over chunk c (c < 8) | 40-41 out_proj^T tiles 2w, 2w+1
 __global__ void __launch_bounds__(THREADS, 1)
 k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues, g2048_tail_weights_t WT, g2048_tail_saved S,
            g2048_tail_grads G, __bf16 *__restrict__ d_o, float *__restrict__ dx_cls, int64_t M, float p_drop, uint64_t seed,
@@ -409,20 +451,104 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
     float *const xm = reinterpret_cast<float *>(L.xc);
     const uint16_t *const masks_wg = reinterpret_cast<const uint16_t *>(S.masks) + (int64_t)blockIdx.x * N_MASK_TILES * 64;
 
+    Ring R;
+    auto issue = [&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < N_UNITS) {
+            constexpr int slot = i % RING;
+            if constexpr (i < 24) {
+                constexpr int j = i % 12;
+                const void *l1 = i < 12 ? WT.a1T : WT.c1T, *l2 = i < 12 ? WT.a2T : WT.c2T;
+                if constexpr (j < 8) fetch_unit<slot>(R, unit_ptr(l2, HID, 32 * (4 * w + j / 2), 256 * (j % 2), lane), NEXT_8_STEPS);
+                else fetch_unit<slot>(R, unit_ptr(l1, HID, 32 * (2 * w + (j - 8) / 2), 256 * ((j - 8) % 2), lane), NEXT_8_STEPS);
+            } else if constexpr (i < 40) {
+                constexpr int c = (i - 24) / 2;
+                if constexpr ((i - 24) % 2 == 0) fetch_unit<slot>(R, unit_ptr(WT.w2T, D, 32 * (4 * c + w), 0, lane), NEXT_8_STEPS);
+                else fetch_unit<slot>(R, unit_ptr(WT.w1T, FF, 32 * (2 * w), FC * c, lane), next_row_tile(FF));
+            } else {
+                fetch_unit<slot>(R, unit_ptr(WT.woT, D, 32 * (2 * w + (i - 40)), 0, lane), NEXT_8_STEPS);
+            }
+        }
+        sched_fence();
+    };
+    issue(std::integral_constant<int, 0>{});
+    issue(std::integral_constant<int, 1>{});
+
     if (tid < 32) {
         const bool ok = m0 + tid < M;
         const float4 v = ok ? reinterpret_cast<const float4 *>(dlogits)[m0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
         L.dl[tid][0] = v.x; L.dl[tid][1] = v.y; L.dl[tid][2] = v.z; L.dl[tid][3] = v.w;
         L.dl[tid][4] = ok ? dvalues[m0 + tid] : 0.f;
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- both heads -> d features (f32, this wave's two tiles)
     f32x16 dfeat[2] = {zero_tile(), zero_tile()};
-    head_bwd<4>(L, (const __bf16 *)WT.a1T, (const __bf16 *)WT.a2T, (const __bf16 *)WT.a3, 0, MT_A1, MT_A2, masks_wg, (__bf16 *)G.dlT,
-                (__bf16 *)G.da2T, (__bf16 *)G.da1T, ld, m0, dfeat, tid, lane, r, h, w);
-    head_bwd<1>(L, (const __bf16 *)WT.c1T, (const __bf16 *)WT.c2T, (const __bf16 *)WT.c3, 4, MT_C1, MT_C2, masks_wg, (__bf16 *)G.dvT,
-                (__bf16 *)G.dc2T, (__bf16 *)G.dc1T, ld, m0, dfeat, tid, lane, r, h, w);
+    auto head = [&](auto u0c, auto nout_c, const __bf16 *w3, int dl_col0, int mt1, int mt2, __bf16 *d3T, __bf16 *d2T, __bf16 *d1T)
+                    __attribute__((always_inline)) {
+        constexpr int U0 = decltype(u0c)::value, N_OUT = decltype(nout_c)::value;
+        // d a2 = (W3^T d out) where a2 > 0 -> xa; d out^T (bf16; rows N_OUT.. of the 32-row buffer stay zero) for the weight gradient
+        if (tid < 32 * N_OUT) {
+            const int oo = tid / 32, row = tid % 32;
+            d3T[packed_off(oo, m0 + row, ld)] = (__bf16)L.dl[row][dl_col0 + oo];
+        }
+        for (int t = 0; t < 4; ++t) {
+            const int mt = 4 * w + t;
+            const uint32_t bits = masks_wg[(mt2 + mt) * 64 + lane];
+            float dlr[N_OUT];
+            for (int oo = 0; oo < N_OUT; ++oo) dlr[oo] = (float)(__bf16)L.dl[r][dl_col0 + oo];
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = 32 * mt + 8 * g + 4 * h;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int oo = 0; oo < N_OUT; ++oo) {
+                    const bf16x4 wv = *reinterpret_cast<const bf16x4 *>(w3 + oo * HID + f0);
+                    for (int q = 0; q < 4; ++q) v[q] = __builtin_fmaf((float)wv[q], dlr[oo], v[q]);
+                }
+                for (int q = 0; q < 4; ++q) v[q] = ((bits >> (4 * g + q)) & 1u) ? v[q] : 0.f;
+                put4(L.xa, S512, r, f0, v);
+            }
+        }
+        lds_barrier();
+        lds_to_T(L.xa, S512, HID, d2T, 0, ld, m0, tid);
+        {   // d a1 = (W2^T d a2) where a1 > 0 -> xb
+            static_for<0, 4>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value, u = U0 + 2 * t;
+                const int mt = 4 * w + t;
+                bf16x8 af[16];
+                issue(std::integral_constant<int, u + DIST>{});
+                load_frags<16>(L.xa, S512, 0, af, r, h);
+                f32x16 acc = mm16<u % RING>(R, af, zero_tile());
+                issue(std::integral_constant<int, u + 1 + DIST>{});
+                load_frags<16>(L.xa, S512, 256, af, r, h);
+                acc = mm16<(u + 1) % RING>(R, af, acc);
+                const uint32_t bits = masks_wg[(mt1 + mt) * 64 + lane];
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+                    for (int q = 0; q < 4; ++q) v[q] = ((bits >> (4 * g + q)) & 1u) ? acc[4 * g + q] : 0.f;
+                    put4(L.xb, S512, r, 32 * mt + 8 * g + 4 * h, v);
+                }
+            });
+        }
+        lds_barrier();
+        lds_to_T(L.xb, S512, HID, d1T, 0, ld, m0, tid);
+        {   // d features += W1^T d a1
+            static_for<0, 2>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value, u = U0 + 8 + 2 * j;
+                bf16x8 af[16];
+                issue(std::integral_constant<int, u + DIST>{});
+                load_frags<16>(L.xb, S512, 0, af, r, h);
+                dfeat[j] = mm16<u % RING>(R, af, dfeat[j]);
+                issue(std::integral_constant<int, u + 1 + DIST>{});
+                load_frags<16>(L.xb, S512, 256, af, r, h);
+                dfeat[j] = mm16<(u + 1) % RING>(R, af, dfeat[j]);
+            });
+        }
+        lds_barrier();  // xa / xb are free again (every wave holds its fragments in registers)
+    };
+    head(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, (const __bf16 *)WT.a3, 0, MT_A1, MT_A2, (__bf16 *)G.dlT,
+         (__bf16 *)G.da2T, (__bf16 *)G.da1T);
+    head(std::integral_constant<int, 12>{}, std::integral_constant<int, 1>{}, (const __bf16 *)WT.c3, 4, MT_C1, MT_C2, (__bf16 *)G.dvT,
+         (__bf16 *)G.dc2T, (__bf16 *)G.dc1T);
 
     // ---- features = bf16(x_mid + dropout(f)): g = bf16(d features) flows into the residual (-> xm, f32) and, masked, into f (-> xa)
     {
@@ -442,32 +568,34 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
             }
         }
     }
-    __syncthreads();
-    lds_to_T(L.xa, S256, D, (__bf16 *)G.df2T, ld, m0, tid);
+    lds_barrier();
+    lds_to_T(L.xa, S256, D, (__bf16 *)G.df2T, 0, ld, m0, tid);
 
     // ---- feed-forward backward, in the forward's chunks: dz = (W2^T df) * [u != 0] / keep;  d h2 += W1^T dz
     {
         bf16x8 xf[16];
         load_frags<16>(L.xa, S256, 0, xf, r, h);
-        const __bf16 *w2T = (const __bf16 *)WT.w2T, *w1T = (const __bf16 *)WT.w1T;
         f32x16 dh[2] = {zero_tile(), zero_tile()};
-#pragma nounroll
-        for (int c = 0; c < FF / FC; ++c) {
+        static_for<0, FF / FC>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value, u1 = 24 + 2 * c, u2 = 25 + 2 * c;
             const int ht = 4 * c + w;
             char *ub = L.u[c & 1];
-            const f32x16 du = tile_gemm<16>(w2T, D, 32 * ht, 0, xf, zero_tile(), r, h);
+            issue(std::integral_constant<int, u1 + DIST>{});
+            const f32x16 du = mm16<u1 % RING>(R, xf, zero_tile());
             const uint32_t bits = masks_wg[(MT_FFN + ht) * 64 + lane];
             for (int g = 0; g < 4; ++g) {
                 float v[4];
                 for (int q = 0; q < 4; ++q) v[q] = ((bits >> (4 * g + q)) & 1u) ? du[4 * g + q] * drop.inv_keep : 0.f;
                 put4(ub, S128, r, 32 * w + 8 * g + 4 * h, v);
             }
-            __syncthreads();
-            lds_to_T(ub, S128, FC, (__bf16 *)G.dzT + (int64_t)(FC * c) * ld, ld, m0, tid);
+            lds_barrier();
+            lds_to_T(ub, S128, FC, (__bf16 *)G.dzT, FC * c, ld, m0, tid);
             bf16x8 uf[8];
             load_frags<8>(ub, S128, 0, uf, r, h);
-            for (int j = 0; j < 2; ++j) dh[j] = tile_gemm<8>(w1T, FF, 32 * (2 * w + j), FC * c, uf, dh[j], r, h);
-        }
+            issue(std::integral_constant<int, u2 + DIST>{});
+            dh[0] = mm8<u2 % RING, 0>(R, uf, dh[0]);
+            dh[1] = mm8<u2 % RING, 1>(R, uf, dh[1]);
+        });
         // d h2 (bf16, as the unfused path hands it to the LayerNorm backward) -> xb
         for (int j = 0; j < 2; ++j)
             for (int g = 0; g < 4; ++g) {
@@ -476,7 +604,7 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
                 put4(L.xb, S256, r, 32 * (2 * w + j) + 8 * g + 4 * h, v);
             }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- LayerNorm backward + residual, one wavefront per row (the arithmetic of k_add_ln_bwd):
     //      dx = g + dLN(d h2);  d(out_proj output) = dropout-masked dx (bf16) -> xa;  gamma / beta partials of this workgroup
@@ -515,28 +643,28 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
             L.red[w][1][4 * lane + q] = db[q];
         }
     }
-    __syncthreads();
+    lds_barrier();
     for (int c = tid; c < 2 * D; c += THREADS) {
         const int which = c / D, col = c - which * D;
         G.ln_partial[(int64_t)blockIdx.x * 2 * D + c] = L.red[0][which][col] + L.red[1][which][col] + L.red[2][which][col] + L.red[3][which][col];
     }
-    lds_to_T(L.xa, S256, D, (__bf16 *)G.daoT, ld, m0, tid);
+    lds_to_T(L.xa, S256, D, (__bf16 *)G.daoT, 0, ld, m0, tid);
 
     // ---- d o = Wo^T d(out_proj output), bf16 rows for the attention backward
     {
         bf16x8 xf[16];
         load_frags<16>(L.xa, S256, 0, xf, r, h);
-        const __bf16 *woT = (const __bf16 *)WT.woT;
-        for (int j = 0; j < 2; ++j) {
+        static_for<0, 2>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, u = 40 + j;
             const int mt = 2 * w + j;
-            const f32x16 acc = tile_gemm<16>(woT, D, 32 * mt, 0, xf, zero_tile(), r, h);
+            const f32x16 acc = mm16<u % RING>(R, xf, zero_tile());
             if (m0 + r < M)
                 for (int g = 0; g < 4; ++g) {
                     bf16x4 pk;
                     for (int q = 0; q < 4; ++q) pk[q] = (__bf16)acc[4 * g + q];
                     *reinterpret_cast<bf16x4 *>(d_o + (m0 + r) * D + 32 * mt + 8 * g + 4 * h) = pk;
                 }
-        }
+        });
     }
 }
 
@@ -545,52 +673,94 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
 // ---------------------------------------------------------------------------------------------------------------------
 struct DwTable {
     g2048_dw_job jobs[G2048_DW_MAX_JOBS];
-    int first_item[G2048_DW_MAX_JOBS + 1];  // prefix sums of (N/32) * (K/32 + has_bias) * slices
+    int first_item[G2048_DW_MAX_JOBS + 1];  // prefix sums of the items of one slice: N-blocks x (K / 64 + has_bias)
     int n_jobs, slices;
     int64_t ld, m_per_slice;
 };
 
-// One wavefront per (job, 32 x 32 output tile, slice of the row axis): both operand fragments are plain 16-byte global
-// loads (the row axis is the contiguous one of both transposed operands), f32 partial tile stored as it is; the slices are
-// summed by g2048_reduce_jobs.  k-tile K/32 of a job with a bias is the bias tile: B = ones, column 0 of the result.
+// One wavefront per (slice of the row axis, job, block of <= 64 x 64 outputs): operands are fragment-packed, so every operand
+// load is one contiguous KB, and a 64 x 64 block needs 2 + 2 fragments per 4 MFMAs (a 32 x 32 tile per wave read 2 per MFMA:
+// 360 MB out of L2 for 5.6 GFLOP).  Slice = blockIdx % slices: workgroups are dealt round-robin over the 8 XCDs, so with 8
+// slices every XCD's L2 only ever sees its own eighth of the row axis of all operands (30 MB in total instead of 8 x 30 MB
+// over the fabric).  f32 partial blocks are stored as they are; the slices are summed by g2048_reduce_jobs.
+// k-block K / 64 of a job with a bias is the bias block: B = ones, column 0 of the result.
 __global__ void __launch_bounds__(THREADS)
 k_dweight_t(DwTable T) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int item = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+    const int slice = blockIdx.x % T.slices;
+    const int item = (blockIdx.x / T.slices) * (THREADS / 64) + (threadIdx.x >> 6);
     if (item >= T.first_item[T.n_jobs]) return;
     int j = 0;
     while (item >= T.first_item[j + 1]) ++j;
     const g2048_dw_job J = T.jobs[j];
-    const int kt_n = J.K / 32 + (J.db ? 1 : 0), nt_n = J.N / 32;
-    int e = item - T.first_item[j];
-    const int slice = e / (nt_n * kt_n);
-    e -= slice * nt_n * kt_n;
-    const int nt = e / kt_n, kt = e - nt * kt_n;
-    const bool bias = kt == J.K / 32;
-    const int64_t mb = slice * T.m_per_slice;
-    const __bf16 *pa = (const __bf16 *)J.dyT + (int64_t)(32 * nt + r) * T.ld + mb + 8 * h;
-    const __bf16 *pb = bias ? pa : (const __bf16 *)J.xT + (int64_t)(32 * kt + r) * T.ld + mb + 8 * h;
+    const int kb_n = J.K / 64 + (J.db ? 1 : 0);
+    const int e = item - T.first_item[j];
+    const int nb = e / kb_n, kb = e - nb * kb_n;
+    const bool bias = kb == J.K / 64;
+    const int nt0 = 2 * nb, nt_cnt = (32 * (nt0 + 1) < J.N) ? 2 : 1;  // (N = 32: one row tile)
+    const int64_t steps_total = T.ld >> 4, s0 = (int64_t)slice * (T.m_per_slice >> 4);
+    const __bf16 *pa0 = (const __bf16 *)J.dyT + ((int64_t)nt0 * steps_total + s0) * 512 + lane * 8;
+    const __bf16 *pa1 = pa0 + (nt_cnt == 2 ? steps_total * 512 : 0);
+    const __bf16 *pb0 = bias ? pa0 : (const __bf16 *)J.xT + ((int64_t)(2 * kb) * steps_total + s0) * 512 + lane * 8;
+    const __bf16 *pb1 = bias ? pa0 : pb0 + steps_total * 512;
     bf16x8 ones;
     for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.0f;
-    f32x16 acc = zero_tile();
-    const int steps = (int)(T.m_per_slice / 16);
-    int s = 0;
-    for (; s + 4 <= steps; s += 4) {
-        bf16x8 a[4], b[4];
+    f32x16 c00 = zero_tile(), c01 = zero_tile(), c10 = zero_tile(), c11 = zero_tile();
+    const int steps = (int)(T.m_per_slice >> 4), groups = steps / 4;
+    struct Frag { bf16x8 a0[4], a1[4], b0[4], b1[4]; };
+    auto load = [&](Frag &f, int g) __attribute__((always_inline)) {
+#pragma unroll
         for (int u = 0; u < 4; ++u) {
-            a[u] = *reinterpret_cast<const bf16x8 *>(pa + 16 * (s + u));
-            b[u] = bias ? ones : *reinterpret_cast<const bf16x8 *>(pb + 16 * (s + u));
+            const int64_t o = (int64_t)(4 * g + u) * 512;
+            f.a0[u] = *reinterpret_cast<const bf16x8 *>(pa0 + o);
+            f.a1[u] = *reinterpret_cast<const bf16x8 *>(pa1 + o);
+            f.b0[u] = bias ? ones : *reinterpret_cast<const bf16x8 *>(pb0 + o);
+            f.b1[u] = bias ? ones : *reinterpret_cast<const bf16x8 *>(pb1 + o);
         }
-        for (int u = 0; u < 4; ++u) acc = mfma(a[u], b[u], acc);
+    };
+    auto mul = [&](const Frag &f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c00 = mfma(f.a0[u], f.b0[u], c00);
+            c01 = mfma(f.a0[u], f.b1[u], c01);
+            c10 = mfma(f.a1[u], f.b0[u], c10);
+            c11 = mfma(f.a1[u], f.b1[u], c11);
+        }
+    };
+    Frag f0, f1;
+    if (groups > 0) load(f0, 0);
+    for (int g = 0; g < groups; g += 2) {
+        if (g + 1 < groups) load(f1, g + 1);
+        mul(f0);
+        if (g + 2 < groups) load(f0, g + 2);
+        if (g + 1 < groups) mul(f1);
     }
-    for (; s < steps; ++s)
-        acc = mfma(*reinterpret_cast<const bf16x8 *>(pa + 16 * s), bias ? ones : *reinterpret_cast<const bf16x8 *>(pb + 16 * s), acc);
+    for (int st = 4 * groups; st < steps; ++st) {
+        const int64_t o = (int64_t)st * 512;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(pa0 + o), a1 = *reinterpret_cast<const bf16x8 *>(pa1 + o);
+        const bf16x8 b0 = bias ? ones : *reinterpret_cast<const bf16x8 *>(pb0 + o), b1 = bias ? ones : *reinterpret_cast<const bf16x8 *>(pb1 + o);
+        c00 = mfma(a0, b0, c00);
+        c01 = mfma(a0, b1, c01);
+        c10 = mfma(a1, b0, c10);
+        c11 = mfma(a1, b1, c11);
+    }
     if (bias) {
         if (r == 0)
-            for (int i = 0; i < 16; ++i) J.db[(int64_t)slice * J.N + 32 * nt + rowof(i, h)] = acc[i];
+            for (int i = 0; i < 16; ++i) {
+                J.db[(int64_t)slice * J.N + 32 * nt0 + rowof(i, h)] = c00[i];
+                if (nt_cnt == 2) J.db[(int64_t)slice * J.N + 32 * (nt0 + 1) + rowof(i, h)] = c10[i];
+            }
     } else {
-        float *out = J.dw + ((int64_t)slice * J.N + 32 * nt) * J.K + 32 * kt + r;
-        for (int i = 0; i < 16; ++i) out[(int64_t)rowof(i, h) * J.K] = acc[i];
+        float *out = J.dw + ((int64_t)slice * J.N + 32 * nt0) * J.K + 64 * kb + r;
+        for (int i = 0; i < 16; ++i) {
+            float *o = out + (int64_t)rowof(i, h) * J.K;
+            o[0] = c00[i];
+            o[32] = c01[i];
+            if (nt_cnt == 2) {
+                o[(int64_t)32 * J.K] = c10[i];
+                o[(int64_t)32 * J.K + 32] = c11[i];
+            }
+        }
     }
 }
 
@@ -643,7 +813,7 @@ extern "C" int g2048_cls_tail_bwd(const float *dlogits, const float *dvalues, co
 }
 
 extern "C" int g2048_dweight_t(const g2048_dw_job *jobs, int n_jobs, int64_t ld, int64_t m, int slices, void *stream) {
-    if (!jobs || n_jobs <= 0 || n_jobs > G2048_DW_MAX_JOBS || slices <= 0 || m <= 0 || m > ld || (ld & 7) || m % (16 * (int64_t)slices))
+    if (!jobs || n_jobs <= 0 || n_jobs > G2048_DW_MAX_JOBS || slices <= 0 || m <= 0 || m > ld || (ld & 15) || m % (16 * (int64_t)slices))
         return G2048_EINVAL;
     DwTable T;
     T.n_jobs = n_jobs;
@@ -653,14 +823,15 @@ extern "C" int g2048_dweight_t(const g2048_dw_job *jobs, int n_jobs, int64_t ld,
     int items = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const g2048_dw_job &J = jobs[j];
-        if (mis16(J.dyT) || mis16(J.xT) || mis16(J.dw) || J.N <= 0 || J.K <= 0 || (J.N & 31) || (J.K & 31) || ((uintptr_t)J.db & 3))
+        if (mis16(J.dyT) || mis16(J.xT) || mis16(J.dw) || J.N <= 0 || J.K <= 0 || (J.N & 31) || (J.K & 63) || ((uintptr_t)J.db & 3))
             return G2048_EINVAL;
         T.jobs[j] = J;
         T.first_item[j] = items;
-        items += (J.N / 32) * (J.K / 32 + (J.db ? 1 : 0)) * slices;
+        items += ((J.N + 63) / 64) * (J.K / 64 + (J.db ? 1 : 0));
     }
     for (int j = n_jobs; j <= G2048_DW_MAX_JOBS; ++j) T.first_item[j] = items;
     const int per_block = THREADS / 64;
-    hipLaunchKernelGGL(k_dweight_t, dim3((unsigned)((items + per_block - 1) / per_block)), dim3(THREADS), 0, (hipStream_t)stream, T);
+    hipLaunchKernelGGL(k_dweight_t, dim3((unsigned)(((items + per_block - 1) / per_block) * slices)), dim3(THREADS), 0, (hipStream_t)stream,
+                       T);
     return done();
 }

@@ -556,7 +556,8 @@ OPT_MAX_GROUPS = 4  # G2048_OPT_MAX_GROUPS
 
 class OptChunk(C.Structure):  # g2048_opt_chunk
     _fields_ = [("param", _vp), ("offset", _i64), ("n", C.c_int32), ("group", C.c_int32), ("shadow", _vp), ("shadow_t", _vp),
-                ("e0", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("reserved", C.c_int32)]
+                ("shadow_p", _vp), ("shadow_tp", _vp), ("e0", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 OPT_CHUNK_BYTES = C.sizeof(OptChunk)
@@ -569,8 +570,8 @@ class OptGroup(C.Structure):  # g2048_opt_group
 def opt_chunk_table(params, offsets, groups, device, shadows=None) -> torch.Tensor:
     """The device-resident chunk table of g2048_opt_step (u8 tensor holding g2048_opt_chunk records): parameter i (a
     contiguous f32 device tensor) has its gradient/moments at element offsets[i] of the flat buffers and belongs to
-    hyper-parameter group groups[i].  ``shadows``: optional {id(parameter): (bf16 copy, bf16 transposed copy or None)} the
-    step keeps up to date."""
+    hyper-parameter group groups[i].  ``shadows``: optional {id(parameter): (bf16 copy, bf16 transposed copy or None[, bf16
+    fragment-packed copy or None, bf16 fragment-packed transposed copy or None])} the step keeps up to date."""
     recs = []
     shadows = shadows or {}
     for p, off, grp in zip(params, offsets, groups):
@@ -578,16 +579,21 @@ def opt_chunk_table(params, offsets, groups, device, shadows=None) -> torch.Tens
             raise NativeError(f"opt_chunk_table: parameter {tuple(p.shape)} {p.dtype} on {p.device} (offset {off}) is not a "
                               "contiguous 16-byte aligned f32 device tensor at a flat offset that is a multiple of 4")
         n = p.numel()
-        sh, sh_t = shadows.get(id(p), (None, None))
-        for t in (sh, sh_t):
+        sh, sh_t, sh_p, sh_tp = (tuple(shadows.get(id(p), ())) + (None,) * 4)[:4]
+        for t in (sh, sh_t, sh_p, sh_tp):
             if t is not None and (t.dtype != torch.bfloat16 or not t.is_cuda or not t.is_contiguous() or t.numel() != n):
                 raise NativeError(f"opt_chunk_table: shadow of a {tuple(p.shape)} parameter must be a contiguous bf16 tensor of {n} elements")
         if sh_t is not None and (p.dim() != 2 or tuple(sh_t.shape) != tuple(p.shape[::-1])):
             raise NativeError("opt_chunk_table: a transposed shadow needs a 2-D parameter and the transposed shape")
+        if sh_p is not None and (p.dim() != 2 or p.shape[0] % 32 or p.shape[1] % 16 or sh_p.data_ptr() % 16):
+            raise NativeError("opt_chunk_table: a packed shadow needs a 2-D parameter with rows % 32 == 0 and cols % 16 == 0")
+        if sh_tp is not None and (p.dim() != 2 or p.shape[1] % 32 or p.shape[0] % 16 or sh_tp.data_ptr() % 16):
+            raise NativeError("opt_chunk_table: a packed transposed shadow needs a 2-D parameter with cols % 32 == 0 and rows % 16 == 0")
         rows, cols = (p.shape[0], p.shape[1]) if p.dim() == 2 else (1, max(n, 1))
         for c0 in range(0, n, OPT_CHUNK):
             recs.append(OptChunk(p.data_ptr() + 4 * c0, off + c0, min(OPT_CHUNK, n - c0), grp, sh.data_ptr() if sh is not None else None,
-                                 sh_t.data_ptr() if sh_t is not None else None, c0, rows, cols, 0))
+                                 sh_t.data_ptr() if sh_t is not None else None, sh_p.data_ptr() if sh_p is not None else None,
+                                 sh_tp.data_ptr() if sh_tp is not None else None, c0, rows, cols, 0))
     arr = (OptChunk * len(recs))(*recs)
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=u8)
     return host.to(device)
@@ -640,6 +646,17 @@ TAIL_MASK_TILES = 96
 DW_MAX_JOBS = 16
 
 
+def pack_fragments(x: torch.Tensor) -> torch.Tensor:
+    """Row-major [rows, cols] (rows % 32 == 0, cols % 16 == 0) -> the fragment-packed layout of include/g2048.h, as a flat tensor."""
+    R, Cc = x.shape
+    return x.reshape(R // 32, 32, Cc // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(-1).contiguous()
+
+
+def unpack_fragments(flat: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """Inverse of ``pack_fragments``: flat packed tensor -> row-major [rows, cols]."""
+    return flat.reshape(rows // 32, cols // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(rows, cols)
+
+
 class TailWeights(C.Structure):
     _fields_ = [(n, _vp) for n in ("wo", "w1", "w2", "a1", "a2", "a3", "c1", "c2", "c3", "bo", "b1", "b2", "ab1", "ab2", "cb1", "cb2",
                                    "ln_g", "ln_b")]
@@ -670,16 +687,24 @@ class TailBuffers:
     """Device buffers of one g2048_cls_tail_fwd / _bwd pair for M rows (allocated once per minibatch size and reused: every
     element that is read is rewritten by each forward / backward; dlT / dvT rows that are never written stay zero)."""
 
+    def unpacked(self, name: str) -> torch.Tensor:
+        """Row-major [rows, ld] view-copy of a packed transposed buffer (tests / debugging)."""
+        t = self.saved[name] if name in self.saved else self.grads[name]
+        return unpack_fragments(t, self.rows[name], self.ld)
+
     def __init__(self, M: int, device):
         bf = torch.bfloat16
         self.M, self.blocks = int(M), (int(M) + 31) // 32
         self.ld = 32 * self.blocks
+        # slices of the row axis in g2048_dweight_t: 8 (one per XCD) when every slice is a whole number of 16-row k-steps
         self.slices = next(s for s in (8, 4, 2, 1) if self.ld % (16 * s) == 0)
         z = lambda *shape, dtype=bf: torch.zeros(shape, dtype=dtype, device=device)
         self.saved = dict(x_mid=z(self.M, 256, dtype=f32), mean=z(self.M, dtype=f32), rstd=z(self.M, dtype=f32),
                           masks=z(self.blocks, TAIL_MASK_TILES, 64, dtype=torch.int16))
-        self.saved.update({k: z(rows, self.ld) for k, rows in _TAIL_SAVED_ROWS.items()})
-        self.grads = {k: z(rows, self.ld) for k, rows in _TAIL_GRAD_ROWS.items()}
+        # transposed activations / gradients, fragment-packed (``unpack_fragments(t, rows, ld)`` gives [rows, ld]): flat tensors
+        self.saved.update({k: z(rows * self.ld) for k, rows in _TAIL_SAVED_ROWS.items()})
+        self.grads = {k: z(rows * self.ld) for k, rows in _TAIL_GRAD_ROWS.items()}
+        self.rows = dict(_TAIL_SAVED_ROWS, **_TAIL_GRAD_ROWS)
         self.grads["ln_partial"] = z(self.blocks, 512, dtype=f32)
         self.saved_c = TailSaved(*[self.saved[n].data_ptr() for n, _ in TailSaved._fields_[:-1]], self.ld)
         self.grads_c = TailGrads(*[self.grads[n].data_ptr() for n, _ in TailGrads._fields_])
@@ -736,15 +761,16 @@ def cls_tail_bwd(dlogits, dvalues, WT: TailWeightsT, buf: TailBuffers, p_drop: f
 
 
 def dweight_t(jobs, ld: int, m: int, slices: int):
-    """jobs: list of (dyT bf16 [N, ld], xT bf16 [K, ld], dw f32 [slices, N, K], db f32 [slices, N] or None)."""
+    """jobs: list of (dyT, xT, dw f32 [slices, N, K], db f32 [slices, N] or None); dyT / xT: fragment-packed bf16 of N * ld / K * ld
+    elements (``pack_fragments`` of the [N, ld] / [K, ld] matrices)."""
     recs = []
     for dyT, xT, dw, db in jobs:
-        N, K = dyT.shape[0], xT.shape[0]
+        N, K = dw.shape[1], dw.shape[2]
         for t, dt, name in ((dyT, torch.bfloat16, "dyT"), (xT, torch.bfloat16, "xT"), (dw, f32, "dw")):
             if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
                 raise NativeError(f"dweight_t: {name} must be a contiguous {dt} device tensor")
-        if dyT.shape[1] != ld or xT.shape[1] != ld or dw.numel() != slices * N * K or (db is not None and db.numel() != slices * N):
-            raise NativeError(f"dweight_t: shapes {tuple(dyT.shape)} x {tuple(xT.shape)} -> {tuple(dw.shape)} do not fit ld={ld}")
+        if dyT.numel() != N * ld or xT.numel() != K * ld or dw.shape[0] != slices or (db is not None and db.numel() != slices * N):
+            raise NativeError(f"dweight_t: {dyT.numel()} x {xT.numel()} elements -> {tuple(dw.shape)} do not fit ld={ld}")
         recs.append(DwJob(dyT.data_ptr(), xT.data_ptr(), dw.data_ptr(), None if db is None else _dev(db, f32, slices * N, "db"), N, K))
     arr = (DwJob * len(recs))(*recs)
     _check(load().g2048_dweight_t(C.cast(arr, _vp), len(recs), int(ld), int(m), int(slices), _stream()), "g2048_dweight_t")

@@ -81,7 +81,8 @@ class FlatAdamWStep:
 
     def adopt_shadows(self, shadows):
         """Keep bf16 shadow copies of parameters up to date from inside the optimiser kernel.  ``shadows``: objects with
-        ``params`` (list), ``views`` (bf16 tensors, same order), ``tviews`` ({index: transposed bf16 tensor}), a ``key``
+        ``params`` (list), ``views`` (bf16 tensors, same order), ``tviews`` ({index: transposed bf16 tensor}), optionally ``pviews`` /
+        ``ptviews`` ({index: fragment-packed bf16 copy of the tensor / of its transpose}), a ``key``
         attribute and ``current_key()`` (what ``hip_ops.Bf16Shadow`` offers); only those whose parameters all belong to this
         optimiser and whose buffers exist are taken.  Each adopted shadow is refreshed once here (a copy) and from then on by
         ``step()``; its ``maintainer`` is set so that it stops copying on its own while its key is current."""
@@ -102,7 +103,8 @@ class FlatAdamWStep:
             shadow_of = {}
             for sh in self._shadows:
                 for i, p in enumerate(sh.params):
-                    shadow_of[id(p)] = (sh.views[i], sh.tviews.get(i))
+                    shadow_of[id(p)] = (sh.views[i], sh.tviews.get(i), getattr(sh, "pviews", {}).get(i),
+                                        getattr(sh, "ptviews", {}).get(i))
             self._table = nv.opt_chunk_table(self.params, self.offsets, self.group_of, self.device, shadow_of)
             self._n_chunks = self._table.numel() // nv.OPT_CHUNK_BYTES
             self._ws = nv.opt_workspace(self._n_chunks, self.device)

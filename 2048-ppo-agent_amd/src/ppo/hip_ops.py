@@ -20,11 +20,15 @@ class Bf16Shadow:
 
     _live = weakref.WeakSet()
 
-    def __init__(self, params, transposed=()):
+    def __init__(self, params, transposed=(), packed=()):
         self.params = list(params)
         self.key, self.flat, self.views = None, None, None
         self.transposed = tuple(transposed)  # indices of 2-D params that also get a [in, out] copy (``tviews[i]``)
         self.tviews = {}
+        # indices of 2-D params that also get fragment-packed copies of the tensor and of its transpose (``pviews[i]``,
+        # ``ptviews[i]``: flat bf16 tensors in the MFMA operand order of include/g2048.h, read by the fused CLS tail kernels)
+        self.packed = tuple(packed)
+        self.pviews, self.ptviews = {}, {}
         # set by an optimiser that rewrites the shadow together with the parameters (optim.flat_step.FlatAdamWStep): the
         # shadow then copies only when its key is stale (someone else changed a parameter), also during a hipGraph capture
         self.maintainer = None
@@ -33,10 +37,10 @@ class Bf16Shadow:
     def __getstate__(self):
         """copy.deepcopy / pickle of an agent: the copy starts cold - no buffers and no maintainer (both belong to the
         original's optimiser, which must not travel with a pickled module) - and registers itself like a new shadow."""
-        return {"params": self.params, "transposed": self.transposed}
+        return {"params": self.params, "transposed": self.transposed, "packed": self.packed}
 
     def __setstate__(self, state):
-        self.__init__(state["params"], state["transposed"])
+        self.__init__(state["params"], state["transposed"], state.get("packed", ()))
 
     def invalidate(self):
         self.key = None
@@ -75,10 +79,18 @@ class Bf16Shadow:
                 self.views = [self.flat[o:o + q.numel()].view(q.shape) for o, q in zip(offs, ps)]
                 self.tviews = {i: torch.empty(ps[i].shape[::-1], dtype=torch.bfloat16, device=ps[0].device)
                                for i in self.transposed}
+                self.pviews = {i: torch.empty(ps[i].numel(), dtype=torch.bfloat16, device=ps[0].device) for i in self.packed}
+                self.ptviews = {i: torch.empty(ps[i].numel(), dtype=torch.bfloat16, device=ps[0].device) for i in self.packed}
             with torch.no_grad():
                 torch._foreach_copy_(self.views, [q.detach() for q in ps])
                 for i, tv in self.tviews.items():
                     tv.copy_(self.views[i].t())
+                if self.pviews:
+                    from ..g2048 import native as nv
+
+                    for i in self.packed:
+                        self.pviews[i].copy_(nv.pack_fragments(self.views[i]))
+                        self.ptviews[i].copy_(nv.pack_fragments(self.views[i].t()))
             # a copy recorded into a hipGraph has not run yet: leave the key stale so that the next eager use copies for real
             self.key = None if (ps[0].is_cuda and torch.cuda.is_current_stream_capturing()) else key
         return self.views
@@ -904,9 +916,12 @@ class TailBufferCache(dict):
 
 class TailPlan:
     """Everything ``_ClsTailHeads`` needs besides its tensor inputs: the f32 master parameters by field name (``TAIL_PARAM_ORDER``),
-    their bf16 shadows (dense for the forward, transposed for the backward) and the buffer cache of the owning module."""
+    their bf16 shadows (fragment-packed: the weight for the forward, its transpose for the backward) and the buffer cache of the owning
+    module."""
 
     def __init__(self, params: dict, dense: dict, transposed: dict, buffer_cache: dict, eps: float, p_drop: float):
+        # dense / transposed: FRAGMENT-PACKED bf16 copies of the weights / of their transposes (flat tensors), except a3 / c3 in
+        # ``dense``, which the kernels read row-major
         self.params, self.dense, self.transposed, self.cache = params, dense, transposed, buffer_cache
         self.eps, self.p_drop = float(eps), float(p_drop)
 

@@ -132,15 +132,15 @@ class PPOAgent(_ActorCritic):
         layer's and runs the node."""
         a, c = list(self.actor), list(self.critic)
         lins = [a[0], a[2], a[4], c[0], c[2], c[4]]
-        if self._head_shadow is None or not self._head_shadow.transposed:
+        if self._head_shadow is None or not self._head_shadow.packed:
             ps = [q for m in lins for q in (m.weight, m.bias) if q is not None]  # a1.w a1.b a2.w a2.b a3.w c1.w c1.b c2.w c2.b c3.w
-            self._head_shadow = Bf16Shadow(ps, transposed=[0, 2, 5, 7])
+            self._head_shadow = Bf16Shadow(ps, packed=[0, 2, 5, 7])
         v = self._head_shadow()
-        tv = self._head_shadow.tviews
+        pv, ptv = self._head_shadow.pviews, self._head_shadow.ptviews
         params = dict(params, a1=a[0].weight, ab1=a[0].bias, a2=a[2].weight, ab2=a[2].bias, a3=a[4].weight, c1=c[0].weight,
                       cb1=c[0].bias, c2=c[2].weight, cb2=c[2].bias, c3=c[4].weight)
-        dense = dict(dense, a1=v[0], a2=v[2], a3=v[4], c1=v[5], c2=v[7], c3=v[9])
-        transposed = dict(transposed, a1=tv[0], a2=tv[2], c1=tv[5], c2=tv[7])
+        dense = dict(dense, a1=pv[0], a2=pv[2], a3=v[4], c1=pv[5], c2=pv[7], c3=v[9])
+        transposed = dict(transposed, a1=ptv[0], a2=ptv[2], c1=ptv[5], c2=ptv[7])
         if not hasattr(self, "_tail_buffers"):
             self._tail_buffers = TailBufferCache()
         plan = TailPlan(params, dense, transposed, self._tail_buffers, eps, p_drop)

@@ -87,9 +87,10 @@ class TransformerEncoder(nn.Module):
                 ps += [l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, l.self_attn.out_proj.weight,
                        l.self_attn.out_proj.bias, l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias]
             last = len(layers) - 1
-            # [in, out] copies: linear2 of every layer (masked input-gradient GEMM); out_proj and linear1 of the LAST layer (the
-            # fused CLS tail's backward, g2048_cls_tail_bwd)
-            self._shadow = Bf16Shadow(ps, transposed=[8 * i + 6 for i in range(len(layers))] + [8 * last + 2, 8 * last + 4])
+            # [in, out] copies: linear2 of every layer (masked input-gradient GEMM); fragment-packed copies (tensor and transpose) of
+            # out_proj, linear1 and linear2 of the LAST layer (the fused CLS tail, g2048_cls_tail_fwd / _bwd)
+            self._shadow = Bf16Shadow(ps, transposed=[8 * i + 6 for i in range(len(layers))],
+                                      packed=[8 * last + 2, 8 * last + 4, 8 * last + 6])
         v = self._shadow()
         return [v[8 * i:8 * i + 8] + [self._shadow.tviews[8 * i + 6]] for i in range(len(layers))]
 
@@ -131,13 +132,13 @@ class TransformerEncoder(nn.Module):
             # update path, CLS-only last layer: everything from out_proj to the heads' outputs is ONE node (g2048_cls_tail_fwd/bwd);
             # the caller's closure adds the heads' parameters and returns (logits, values)
             i_last = len(self.encoder.layers) - 1
-            tv = self._shadow.tviews
+            pv, ptv = self._shadow.pviews, self._shadow.ptviews
             n2 = layer.norm2
             return tail_heads(a, x, dict(wo=attn.out_proj.weight, bo=attn.out_proj.bias, ln_g=n2.weight, ln_b=n2.bias,
                                          w1=layer.linear1.weight, b1=layer.linear1.bias, w2=layer.linear2.weight,
                                          b2=layer.linear2.bias),
-                              dict(wo=sh[2], w1=sh[4], w2=sh[6]), dict(wo=tv[8 * i_last + 2], w1=tv[8 * i_last + 4], w2=sh[8]),
-                              n2.eps, p), None
+                              {k: pv[8 * i_last + o] for k, o in (("wo", 2), ("w1", 4), ("w2", 6))},
+                              {k: ptv[8 * i_last + o] for k, o in (("wo", 2), ("w1", 4), ("w2", 6))}, n2.eps, p), None
         if sh[0] is not None and a.dtype == torch.bfloat16 and _fused_norm_ok(x, None) \
                 and layer.linear1.out_features % 8 == 0 and layer.linear1.out_features <= 2048:
             # update path: out_proj + add + LayerNorm, linear1 + ReLU + dropout, linear2 + add + LayerNorm as three ops

@@ -371,6 +371,8 @@ typedef struct {
     float *param; int64_t offset; int32_t n; int32_t group;
     void *shadow;      /* optional bf16 copy of the tensor (dense, same element order): the chunk's piece is refreshed in place */
     void *shadow_t;    /* optional bf16 copy of the TRANSPOSED 2-D tensor [cols][rows] */
+    void *shadow_p;    /* optional bf16 copy of the 2-D tensor in the fragment-packed layout (see g2048_tail_saved); rows % 32 == 0, cols % 16 == 0 */
+    void *shadow_tp;   /* optional fragment-packed bf16 copy of the TRANSPOSED tensor; cols % 32 == 0, rows % 16 == 0 */
     int32_t e0;        /* element index of the chunk's first element inside its tensor */
     int32_t rows, cols; /* shape of the 2-D tensor (only read when shadow_t is set) */
     int32_t reserved;
@@ -393,21 +395,26 @@ int g2048_opt_step(const g2048_opt_chunk *chunks, int n_chunks, const float *gra
  * g2048_dweight_t all weight / bias gradients from the transposed operands the two leave behind.
  * Weights: bf16 copies in nn.Linear's [out][in] layout (16-byte aligned), biases and LayerNorm parameters f32. */
 typedef struct {
-    const void *wo, *w1, *w2;           /* out_proj [256][256], linear1 [1024][256], linear2 [256][1024] */
-    const void *a1, *a2, *a3;           /* actor  [512][256], [512][512], [4][512] (no bias) */
-    const void *c1, *c2, *c3;           /* critic [512][256], [512][512], [1][512] (no bias) */
+    const void *wo, *w1, *w2;           /* out_proj [256][256], linear1 [1024][256], linear2 [256][1024]: packed */
+    const void *a1, *a2, *a3;           /* actor  [512][256], [512][512] packed; [4][512] row-major (no bias) */
+    const void *c1, *c2, *c3;           /* critic [512][256], [512][512] packed; [1][512] row-major (no bias) */
     const float *bo, *b1, *b2, *ab1, *ab2, *cb1, *cb2;
     const float *ln_g, *ln_b;           /* norm2 */
 } g2048_tail_weights;
-/* the backward multiplies with the TRANSPOSED weights ([in][out], bf16; g2048_opt_step keeps such shadows current) */
+/* the backward multiplies with the TRANSPOSED weights ([in][out], bf16, packed; g2048_opt_step keeps such shadows current) */
 typedef struct {
     const void *woT, *w1T, *w2T;        /* [256][256], [256][1024], [1024][256] */
     const void *a1T, *a2T, *a3;         /* [256][512], [512][512]; a3 as it is, [4][512] */
     const void *c1T, *c2T, *c3;         /* [256][512], [512][512]; c3 as it is, [1][512] */
     const float *ln_g;
 } g2048_tail_weights_t;
-/* What the forward leaves for the backward and for the weight gradients.  ld = leading dimension (elements) of every
- * transposed buffer, a multiple of 32 and >= 32 * ceil(M / 32); columns M..ld-1 are written as zero.
+/* Fragment-packed layout ("packed" below) of a bf16 matrix X[rows][cols], rows % 32 == 0, cols % 16 == 0 -- the order in
+ * which a wavefront consumes X as an MFMA operand, one contiguous KB per wave-instruction:
+ *   offset(row, col) = ((((row / 32) * (cols / 16) + col / 16) * 2 + (col / 8) % 2) * 32 + row % 32) * 8 + col % 8.
+ * The weights of g2048_tail_weights / g2048_tail_weights_t (except a3, c3: row-major) and every transposed activation buffer
+ * below are stored that way; g2048_opt_step maintains packed shadows of parameters (g2048_opt_chunk.shadow_p / shadow_tp). */
+/* What the forward leaves for the backward and for the weight gradients.  ld = number of columns of every transposed
+ * buffer, a multiple of 32 and >= 32 * ceil(M / 32); columns M..ld-1 are written as zero.
  * masks: u16 [ceil(M/32)][G2048_TAIL_MASK_TILES][64], one bit per element of an MFMA accumulator tile (private layout). */
 #define G2048_TAIL_MASK_TILES 96
 typedef struct {
@@ -440,7 +447,8 @@ int g2048_cls_tail_bwd(const float *dlogits, const float *dvalues, const g2048_t
 /* Weight gradients from transposed operands, all jobs in one launch: for job j,
  * dw[s][n][k] = sum over the s-th of `slices` equal pieces of the row axis of dyT[n][m] * xT[k][m]   (f32 [slices][N][K]),
  * db[s][n]    = the same sum of dyT[n][m]                                                        (f32 [slices][N], or NULL);
- * dyT bf16 [N][ld], xT bf16 [K][ld], N and K multiples of 32, m (rows used, <= ld) a multiple of 16 * slices.  The slices are
+ * dyT bf16 [N][ld], xT bf16 [K][ld], both packed; N a multiple of 32, K of 64, m (rows used, <= ld) a multiple of 16 * slices
+ * (8 slices put each slice on one XCD).  The slices are
  * summed by g2048_reduce_jobs.  Replaces dY^T X (torch: `dy.t() @ x`) and the bias column sums in the backward of every
  * nn.Linear of the tail (reference: loss.backward() at src/ppo/ppo_trainer.py:410-414).  jobs: host array, read during the call. */
 #define G2048_DW_MAX_JOBS 16

@@ -131,6 +131,7 @@ def test_optimiser_keeps_bf16_shadows_current(dev, tmp_path, monkeypatch):
     mine = {id(p) for p in agent.parameters()}
     shadows = [s for s in Bf16Shadow._live if s.views is not None and all(id(p) in mine for p in s.params)]
     assert len(shadows) >= 2 and all(s.maintainer is tr._flat_step for s in shadows)  # encoder layers + heads
+    assert sum(len(s.packed) for s in shadows) == 7  # last layer's out_proj / linear1 / linear2 + four head matrices
     def check():
         for s in shadows:
             assert s.key == s.current_key()
@@ -138,6 +139,9 @@ def test_optimiser_keeps_bf16_shadows_current(dev, tmp_path, monkeypatch):
                 assert torch.equal(v, p.detach().to(torch.bfloat16)), i
             for i, tv in s.tviews.items():
                 assert torch.equal(tv, s.params[i].detach().to(torch.bfloat16).t()), i
+            for i in s.packed:  # fragment-packed copies of the tensor and of its transpose (the fused CLS tail's operands)
+                ref = s.params[i].detach().to(torch.bfloat16)
+                assert torch.equal(s.pviews[i], nv.pack_fragments(ref)) and torch.equal(s.ptviews[i], nv.pack_fragments(ref.t())), i
     check()
     before = [p.detach().clone() for p in agent.parameters()]
     tr.use_hip_graph = False  # an eager minibatch takes the same optimiser path

@@ -34,8 +34,10 @@ def _params(dev, seed=0):
 
 def _plan(P, p_drop, cache=None):
     w = [k for k in SHAPES if len(SHAPES[k]) == 2]
-    dense = {k: P[k].detach().to(torch.bfloat16).contiguous() for k in w}
-    transposed = {k: dense[k].t().contiguous() for k in w}
+    bf = {k: P[k].detach().to(torch.bfloat16).contiguous() for k in w}
+    # fragment-packed copies of the weights / of their transposes (what the optimiser kernel maintains); a3 / c3 stay row-major
+    dense = {k: (bf[k] if k in ("a3", "c3") else nv.pack_fragments(bf[k])) for k in w}
+    transposed = {k: nv.pack_fragments(bf[k].t()) for k in w if k not in ("a3", "c3")}
     return TailPlan(P, dense, transposed, TailBufferCache() if cache is None else cache, 1e-5, p_drop)
 
 
@@ -68,7 +70,7 @@ def _reference(P, o, x, p, seed, buf):
     M = o.shape[0]
     inv = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
     k1, k2, k3 = (torch.from_numpy(_keep(seed, s, M, c, p)).to(dev).float() * inv for s, c in ((1, 256), (2, 1024), (3, 256)))
-    act = {k: (buf.saved[k][:, :M].t() != 0).float() for k in ("uT", "a1T", "a2T", "c1T", "c2T")}
+    act = {k: (buf.unpacked(k)[:, :M].t() != 0).float() for k in ("uT", "a1T", "a2T", "c1T", "c2T")}
     assert bool(((act["uT"] == 0) | (k2 != 0)).all())  # every active hidden unit is one the hash keeps
     a = F.linear(o, W["wo"], W["bo"])
     x_mid = x + a * k1
@@ -120,28 +122,32 @@ def test_cls_tail_node_matches_torch(dev, M, p):
     assert not buf.busy
     assert all(v < 2e-2 for v in err.values()), {k: round(v, 4) for k, v in err.items()}
     # columns past M of the transposed operands are zero (the weight-gradient kernel sums over all ld columns)
-    for name, t in list(buf.saved.items()) + list(buf.grads.items()):
-        if t.dim() == 2 and t.shape[1] == buf.ld and t.dtype == torch.bfloat16:
-            assert not bool(t[:, M:].any()), name
+    for name in buf.rows:
+        assert not bool(buf.unpacked(name)[:, M:].any()), name
 
 
 def test_dweight_t_matches_matmul(dev):
-    """g2048_dweight_t: dW = dY^T X and the bias row sums from transposed operands, all slices summed, vs torch in f32."""
+    """g2048_dweight_t: dW = dY^T X and the bias row sums from fragment-packed transposed operands, all slices summed, vs torch in
+    f32; a 32-row dY^T (one row tile per block) and the pack / unpack helpers round-trip."""
     torch.manual_seed(3)
-    ld, m, slices = 256, 256, 4
+    ld, m, slices = 256, 256, 8
     jobs, want = [], []
-    for N, K, bias in ((64, 32, True), (32, 96, False), (128, 128, True)):
+    for N, K, bias in ((64, 64, True), (32, 128, False), (128, 192, True)):
         dyT = torch.randn(N, ld, device=dev).to(torch.bfloat16)
         xT = torch.randn(K, ld, device=dev).to(torch.bfloat16)
+        assert torch.equal(nv.unpack_fragments(nv.pack_fragments(dyT), N, ld), dyT)
         dw = torch.full((slices, N, K), float("nan"), device=dev)
         db = torch.full((slices, N), float("nan"), device=dev) if bias else None
-        jobs.append((dyT, xT, dw, db))
+        jobs.append((nv.pack_fragments(dyT), nv.pack_fragments(xT), dw, db))
         want.append((dyT.float() @ xT.float().t(), dyT.float().sum(1)))
     nv.dweight_t(jobs, ld, m, slices)
     for (dyT, xT, dw, db), (w_ref, b_ref) in zip(jobs, want):
         torch.testing.assert_close(dw.sum(0), w_ref, rtol=1e-4, atol=1e-3)
         if db is not None:
             torch.testing.assert_close(db.sum(0), b_ref, rtol=1e-4, atol=1e-3)
+    nv.dweight_t(jobs[:1], ld, 96, 2)  # a shorter row range in two slices of 3 k-steps each: the remainder loop
+    torch.testing.assert_close(jobs[0][2][:2].sum(0), nv.unpack_fragments(jobs[0][0], 64, ld)[:, :96].float()
+                               @ nv.unpack_fragments(jobs[0][1], 64, ld)[:, :96].float().t(), rtol=1e-4, atol=1e-3)
     with pytest.raises(nv.NativeError):
         nv.dweight_t(jobs, ld, 250, slices)  # rows not a multiple of 16 * slices
 
