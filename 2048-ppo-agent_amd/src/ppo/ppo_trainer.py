@@ -124,8 +124,9 @@ class _GraphedFwdBwd:
     Build it while no autograd graph over the agent's parameters is alive (see ``PPOTrainer._eager_fwd_bwd``).
     Dropout draws fresh masks on every replay (philox offsets for PyTorch's kernels, ``graph_seed_state`` for ours)."""
 
-    def __init__(self, trainer: "PPOTrainer", M: int, sample: dict):
+    def __init__(self, trainer: "PPOTrainer", M: int, sample: dict, capture_allreduce: bool = False):
         self.tr, self.M = trainer, M
+        self.allreduce_captured = bool(capture_allreduce)
         dev = trainer.device
         self.static = {k: torch.empty_like(v) for k, v in sample.items()}
         for k, v in sample.items():
@@ -150,6 +151,8 @@ class _GraphedFwdBwd:
             self.out = self._fwd_bwd()
             if trainer._flat_grad is not None:
                 trainer._collect_grads(point_grads=False)  # graph-owned gradients -> all-reduce bucket, one copy
+                if capture_allreduce:
+                    trainer._allreduce_bucket()  # the step's one collective as a node of the graph
         Bf16Shadow.invalidate_all()  # nothing was copied during the capture itself
         # the gradients the replay writes (graph pool) / the tensors the optimizer reads after a replay
         self.grads = [p.grad for p in trainer.agent.parameters()]
@@ -189,7 +192,8 @@ class PPOTrainer:
                  max_samples_per_epoch: int = None, shuffle_on_reset: bool = False,
                  rollout_amp: Optional[bool] = None,
                  log_dir: str = "logs", use_hip_graph: Optional[bool] = None, rollout_mode: Optional[str] = None,
-                 rollout_horizon: Optional[int] = None):
+                 rollout_horizon: Optional[int] = None, allreduce_dtype: Optional[str] = None,
+                 allreduce_in_graph: Optional[bool] = None):
         self.agent = agent.to(device)
         self.batch_runner = batch_runner
         self.rollout_buffer = rollout_buffer
@@ -243,6 +247,24 @@ class PPOTrainer:
         self.rank = dist.get_rank() if self.world > 1 else 0
         self._group = dist.group.WORLD if self.world > 1 else None
         self._flat_grad = None
+        # The one collective per optimiser step.  allreduce_dtype "float32" (default: exact mean of the ranks' f32 gradients) or
+        # "bfloat16" (G2048_ALLREDUCE_DTYPE=bf16): the bucket travels as bf16 -- 7.9 MB instead of 15.8 MB per step over xGMI, two
+        # cast launches extra; gradients are still loss-scaled there, bf16 has f32's exponent range, so nothing overflows and
+        # every element keeps 8 significant bits (what the bf16 backward produced it with anyway).
+        if allreduce_dtype is None:
+            allreduce_dtype = os.environ.get("G2048_ALLREDUCE_DTYPE", "float32").strip().lower()
+        allreduce_dtype = {"bf16": "bfloat16", "fp32": "float32", "f32": "float32"}.get(allreduce_dtype, allreduce_dtype)
+        if allreduce_dtype not in ("float32", "bfloat16"):
+            raise ValueError(f"allreduce_dtype must be 'float32' or 'bfloat16', got {allreduce_dtype!r}")
+        self.allreduce_dtype = torch.bfloat16 if allreduce_dtype == "bfloat16" else torch.float32
+        self._comm_buf = None
+        # allreduce_in_graph (G2048_ALLREDUCE_IN_GRAPH=1; opt-in): capture the collective inside the update's hipGraph (RCCL
+        # collectives are capturable), so that a replay launches it without host involvement.  If that capture fails the graph is
+        # captured again WITHOUT the collective (never the eager update), and ``allreduce_in_graph_fallback`` says why.
+        if allreduce_in_graph is None:
+            allreduce_in_graph = os.environ.get("G2048_ALLREDUCE_IN_GRAPH", "0").strip().lower() in ("1", "true", "yes", "on")
+        self.allreduce_in_graph = bool(allreduce_in_graph) and self.world > 1 and self.device.type == "cuda"
+        self.allreduce_in_graph_fallback = None
         # clip + AdamW + GradScaler bookkeeping as three launches over flat buffers (g2048_opt_step) for the reference's
         # default optimiser on the device; anything else (LAMB, Adam, CPU) takes the PyTorch calls of the reference
         self._flat_step = None
@@ -332,12 +354,25 @@ class PPOTrainer:
         # fresh gradients every step: backward then writes them without an accumulate kernel per parameter
         self.optimizer.zero_grad(set_to_none=True)
 
-    def _allreduce_grads(self):
+    def _allreduce_grads(self, collective: bool = True):
+        """Gather this step's gradients into the flat bucket and average it over the ranks (``collective`` False: the captured
+        graph already did the second part)."""
         if self._flat_grad is not None:
             self._collect_grads()  # no-op for gradients that already live in the bucket (hipGraph replay)
-        if self.world > 1:
+        if self.world > 1 and collective:
+            self._allreduce_bucket()
+
+    def _allreduce_bucket(self):
+        """mean over ranks of the flat gradient bucket, in place: ONE collective (f32, or bf16 on the wire)."""
+        if self.allreduce_dtype == torch.bfloat16:
+            if self._comm_buf is None or self._comm_buf.device != self._flat_grad.device:
+                self._comm_buf = torch.empty_like(self._flat_grad, dtype=torch.bfloat16)
+            self._comm_buf.copy_(self._flat_grad)
+            dist.all_reduce(self._comm_buf, op=dist.ReduceOp.SUM, group=self._group)
+            self._flat_grad.copy_(self._comm_buf)
+        else:
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self._group)
-            self._flat_grad.div_(self.world)
+        self._flat_grad.div_(self.world)
 
     def _global_max(self, value: int) -> int:
         t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
@@ -435,6 +470,15 @@ class PPOTrainer:
 
     def _build_graph(self, gkey, batch_size: int, sample: dict):
         """Capture the update for this minibatch layout; on failure fall back to eager mode for good (None)."""
+        if self.allreduce_in_graph and self.allreduce_in_graph_fallback is None:
+            try:
+                self._graphs[gkey] = _GraphedFwdBwd(self, batch_size, sample, capture_allreduce=True)
+                return self._graphs[gkey]
+            except Exception as e:  # capture again without the collective (below): never the eager update because of this option
+                logger.warning("capturing the gradient all-reduce inside the hipGraph failed (%s); capturing without it", e)
+                self.allreduce_in_graph_fallback = repr(e)
+                Bf16Shadow.invalidate_all()
+                self.optimizer.zero_grad(set_to_none=True)
         try:
             self._graphs[gkey] = _GraphedFwdBwd(self, batch_size, sample)
         except Exception as e:  # the eager path computes the same thing, only slower: never lose a run
@@ -577,7 +621,7 @@ class PPOTrainer:
                         gkey = (batch_size, obs.dtype, tuple(obs.shape[1:]))
                         graphed = self._graphs.get(gkey) or self._build_graph(gkey, batch_size, sample)
                     stats, kl = graphed.run(sample) if graphed is not None else self._loss_backward(**sample)
-                self._allreduce_grads()
+                self._allreduce_grads(collective=not (graphed is not None and graphed.allreduce_captured))
                 if self._flat_step is not None:
                     self._flat_step.adopt_shadows(list(Bf16Shadow._live))  # (no-op once they are adopted)
                     self._flat_step.step(self.max_grad_norm, self.scaler if self.use_amp else None)
@@ -628,6 +672,12 @@ class PPOTrainer:
         # the rollout forward's own capture (agents with ``rollout_graph_ok``): why it runs eagerly, if it does
         if self.rollout_graph_fallback:
             metrics["rollout_graph_fallback"] = self.rollout_graph_fallback
+        if self.world > 1:
+            metrics["allreduce"] = {"dtype": str(self.allreduce_dtype).replace("torch.", ""), "bytes": int(
+                self._flat_grad.numel() * (2 if self.allreduce_dtype == torch.bfloat16 else 4)) if self._flat_grad is not None else 0,
+                "in_graph": bool(self.allreduce_in_graph and self.allreduce_in_graph_fallback is None and self._graphs)}
+            if self.allreduce_in_graph_fallback:
+                metrics["allreduce"]["in_graph_fallback"] = self.allreduce_in_graph_fallback
         if self.lr_scheduler is not None:
             self.writer.add_scalar("train/lr", self.lr_scheduler.get_last_lr()[0], self.total_timesteps)
         self.writer.add_scalar("train/total_epochs", self.total_epochs, self.total_timesteps)

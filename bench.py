@@ -406,6 +406,15 @@ def main():
         **({"DRYRUN": "all ranks shared one GPU over gloo: control-flow rehearsal, not a measurement"} if dryrun else {}),
         "update_minibatches_per_step": trainer.total_update_steps // max(args.steps + args.warmup, 1),
     }
+    if world > 1:  # every rank must have run the same number of optimiser steps (= collectives)
+        t = torch.tensor([trainer.total_update_steps], dtype=torch.int64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        out["update_steps_per_rank"] = [int(x.item()) for x in allt]
+        if len(set(out["update_steps_per_rank"])) != 1:
+            raise SystemExit(f"ranks ran different numbers of optimiser steps: {out['update_steps_per_rank']}")
+        if "allreduce" in last_metrics:
+            out["allreduce"] = last_metrics["allreduce"]
     if trainer.hip_graph_fallback:
         out["hip_graph_fallback"] = trainer.hip_graph_fallback
     if trainer.rollout_graph_fallback:

@@ -75,6 +75,20 @@ def _worker(rank, world, port, results):
         got = torch.cat([p.grad.flatten() for p in agent.parameters()])
         assert torch.equal(got, tr._flat_grad), "p.grad must alias the flat bucket"
         np.testing.assert_allclose(got.numpy(), want.numpy(), atol=1e-6, rtol=1e-5)
+        # the same step with the bucket travelling as bf16 (allreduce_dtype="bfloat16"): equal to the f32 result up to one bf16
+        # rounding of each rank's contribution (relative 2^-8 per element, of the larger of the two summands)
+        tr.allreduce_dtype = torch.bfloat16
+        tr._zero_grad()
+        tr._compute_ppo_loss(boards[sl], actions[sl], masks[sl], old_lp[sl], adv[sl], ret[sl])[0].backward()
+        mine = torch.cat([p.grad.flatten() for p in agent.parameters()]).clone()
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        tr._allreduce_grads()
+        got16 = torch.cat([p.grad.flatten() for p in agent.parameters()])
+        bound = sum(b.abs() for b in both) / world * 2.0 ** -7 + 1e-12
+        assert bool(((got16 - want).abs() <= bound + 1e-6 * want.abs()).all()), "bf16 bucket outside bf16 rounding of the f32 mean"
+        assert tr._comm_buf is not None and tr._comm_buf.dtype == torch.bfloat16
+        tr.allreduce_dtype = torch.float32
 
         # global z-score == single-process z-score of the concatenation
         full = torch.randn(101, generator=g) * 3 + 1

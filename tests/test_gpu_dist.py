@@ -146,3 +146,27 @@ def test_two_ranks_on_one_gpu(dev):
         mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
         r = dict(results)
         assert r[0] == r[1] and r[0][0] > 0
+
+
+def test_bench_two_rank_dryrun_reaches_the_json_line(dev, tmp_path):
+    """bench.py --gpus 2 under G2048_BENCH_DRYRUN=1 (both ranks on this GPU, gloo): launched the way the driver launches it, it
+    must reach its JSON line with n_gpus 2 and the same number of optimiser steps on both ranks (rehearsal of the multi-GPU
+    control flow: sharding, the global sample budget, the gradient collective, the reductions of the extras)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, G2048_BENCH_DRYRUN="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--boards", "2048", "--train-batch", "512", "--epochs", "1", "--no-extras", "--no-cpu-baseline", "--roofline-boards",
+           "65536"]
+    p = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and "DRYRUN" in out and out["config"]["global_boards"] == 4096
+    assert len(out["update_steps_per_rank"]) == 2 and len(set(out["update_steps_per_rank"])) == 1
+    assert out["update_minibatches_per_step"] >= 1 and out["value"] > 0 and out["allreduce"]["dtype"] == "float32"
