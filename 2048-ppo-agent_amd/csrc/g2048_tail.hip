@@ -63,8 +63,19 @@ struct Drop {
     uint32_t s0, s1, thr;
     float inv_keep;
     __device__ __forceinline__ Drop site(uint32_t k) const { return Drop{s0 + k * 0x632BE5ABu, s1 ^ (k * 0x7F4A7C15u), thr, inv_keep}; }
-    __device__ __forceinline__ float apply(float v, uint64_t idx) const {
-        return thr ? (keep_elem(s0, s1, thr, idx) ? v * inv_keep : 0.0f) : v;
+    // four consecutive elements idx .. idx + 3 (idx a multiple of 4): one hash per PAIR, its two 16-bit halves compared with the
+    // threshold at 16-bit resolution (the convention of g2048_relu_dropout_fwd): half the vector instructions of four full hashes
+    __device__ __forceinline__ void apply4(float v[4], uint64_t idx) const {
+        if (!thr) return;
+        const uint32_t thr16 = thr >> 8;
+        for (int pr = 0; pr < 2; ++pr) {
+            const uint64_t id = (idx >> 1) + pr;
+            uint32_t x = (uint32_t)id * 0x9E3779B1u ^ s0;
+            x ^= (uint32_t)(id >> 32) * 0x85EBCA77u + s1;
+            x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+            v[2 * pr] = (x & 0xFFFFu) >= thr16 ? v[2 * pr] * inv_keep : 0.0f;
+            v[2 * pr + 1] = (x >> 16) >= thr16 ? v[2 * pr + 1] * inv_keep : 0.0f;
+        }
     }
 };
 __device__ __forceinline__ Drop make_drop(uint64_t seed, const uint64_t *seed_state, float p_drop) {
@@ -124,16 +135,23 @@ __device__ __forceinline__ void put4(char *buf, int stride, int r, int col, cons
 __device__ __forceinline__ int64_t packed_off(int row, int64_t col, int64_t cols) {
     return ((((int64_t)(row >> 5) * (cols >> 4) + (col >> 4)) * 2 + ((col >> 3) & 1)) * 32 + (row & 31)) * 8 + (col & 7);
 }
-// the transposed copy the weight-gradient kernel reads, X^T[f0 + f][m0 + row] = buf[row][f] for f < nfeat, row < 32, stored
-// fragment-packed with leading dimension (columns) ld: 16-byte stores of 8 rows each, consecutive threads = consecutive slots.
-// Call between two barriers; nfeat and f0 multiples of 32.
-__device__ __forceinline__ void lds_to_T(const char *buf, int stride, int nfeat, __bf16 *__restrict__ dstT, int f0, int64_t ld,
-                                         int64_t m0, int tid) {
-    for (int e = tid; e < nfeat * 4; e += THREADS) {
-        const int f = e % nfeat, g = e / nfeat;
-        bf16x8 v;
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const __bf16 *>(buf + (8 * g + j) * stride + 2 * f);
-        *reinterpret_cast<bf16x8 *>(dstT + packed_off(f0 + f, m0 + 8 * g, ld)) = v;
+// the transposed copy the weight-gradient kernel reads, X^T[f0 + f][m0 + row] = buf[row][f] for f < NFEAT, row < 32, stored
+// fragment-packed with `steps` = ld / 16 k-steps per row tile: 16-byte stores of 8 rows each, consecutive threads = consecutive
+// slots.  Call between two barriers; NFEAT and f0 multiples of 32, m0 a multiple of 32.  32-bit offsets (buffers < 2^31 elements).
+template <int NFEAT>
+__device__ __forceinline__ void lds_to_T(const char *buf, int stride, __bf16 *__restrict__ dstT, int f0, int steps, int step0, int tid) {
+    static_assert(NFEAT % 64 == 0 && (NFEAT & (NFEAT - 1)) == 0, "feature count");
+#pragma unroll
+    for (int e = tid; e < NFEAT * 4; e += THREADS) {
+        const int f = e & (NFEAT - 1), g = e / NFEAT, F = f0 + f;
+        const char *src = buf + 8 * g * stride + 2 * f;
+        uint32_t wv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            wv[q] = (uint32_t)*reinterpret_cast<const uint16_t *>(src + (2 * q) * stride) |
+                    ((uint32_t)*reinterpret_cast<const uint16_t *>(src + (2 * q + 1) * stride) << 16);
+        const uint32_t off = ((((uint32_t)(F >> 5) * steps + step0 + (g >> 1)) * 2 + (g & 1)) * 32 + (F & 31)) * 8;
+        *reinterpret_cast<uint4 *>(dstT + off) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
     }
 }
 
@@ -144,7 +162,15 @@ struct TailLds {
     char u[2][TB * S128];   // feed-forward hidden chunk (128 units), double-buffered
     float red[4][2][D];     // backward: LayerNorm gradient partials of the four waves
     float dl[TB][8];        // backward: d logits (4) and d value of the tile's rows
+    // staged once at kernel start, so that no tile waits for a dependent global load in front of its MFMAs (28 bias tiles forward,
+    // 48 mask words backward at ~1 us of exposed L2 latency each)
+    union {
+        float bias[D + FF + D + 4 * HID];            // forward: bo | b1 | b2 | ab1 | ab2 | cb1 | cb2
+        uint16_t masks[G2048_TAIL_MASK_TILES * 64];  // backward: this workgroup's ReLU / dropout bit words
+    };
+    __bf16 w3[5 * HID];     // a3 (4 rows) | c3 (1 row)
 };
+constexpr int BO_BO = 0, BO_B1 = D, BO_B2 = D + FF, BO_AB1 = 2 * D + FF, BO_AB2 = BO_AB1 + HID, BO_CB1 = BO_AB2 + HID, BO_CB2 = BO_CB1 + HID;
 static_assert(sizeof(TailLds) <= 160 * 1024, "LDS budget");
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -215,6 +241,7 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * TB, ld = S.ld;
+    const int steps_ld = (int)(ld >> 4), step_m0 = (int)(m0 >> 4);
     const bool valid = m0 + r < M;  // this lane's row in the accumulator layout
     const Drop drop = make_drop(seed, seed_state, p_drop);
     float *const xm = reinterpret_cast<float *>(L.xc);
@@ -240,24 +267,63 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
         }
         sched_fence();
     };
+    // ---- prologue.  Vector-memory loads return in order: a load consumed right after the ring's fetches would wait for all of
+    // them, and a loop of load -> LDS write pairs is one exposed L2 round trip per iteration (35 of them in the first version
+    // of this prologue).  So: every load of the prologue first, into registers; then the ring's first two units; then the LDS
+    // writes, which wait for nothing younger than themselves.
+    uint4 in_o[4];
+    float4 in_x[8];
+    float in_b[14];
+    bf16x8 in_w3[2];
+    {
+        const float *src[7] = {W.bo, W.b1, W.b2, W.ab1, W.ab2, W.cb1, W.cb2};
+        const int len[7] = {D, FF, D, HID, HID, HID, HID};
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int i = 0; i < len[k] / THREADS; ++i) in_b[n++] = src[k][tid + i * THREADS];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * THREADS;  // 320 vectors of 8: a3 rows 0..3, then c3
+            in_w3[i] = e < 4 * HID / 8 ? reinterpret_cast<const bf16x8 *>(W.a3)[e]
+                                       : reinterpret_cast<const bf16x8 *>(W.c3)[e < 5 * HID / 8 ? e - 4 * HID / 8 : 0];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = 8 * p + (tid >> 5), ch = tid & 31;
+            in_o[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (m0 + row < M) in_o[p] = *reinterpret_cast<const uint4 *>(o + (m0 + row) * D + 8 * ch);
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = 4 * p + (tid >> 6), c4 = tid & 63;
+            in_x[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + row < M) in_x[p] = *reinterpret_cast<const float4 *>(x_cls + (m0 + row) * x_rs + 4 * c4);
+        }
+    }
+    sched_fence();
     issue(std::integral_constant<int, 0>{});
     issue(std::integral_constant<int, 1>{});
-
-    // ---- the tile's inputs: attention output rows -> xa (bf16), residual CLS rows -> xm (f32); rows past M are zero
-    for (int p = 0; p < 4; ++p) {
-        const int row = 8 * p + (tid >> 5), ch = tid & 31;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (m0 + row < M) v = *reinterpret_cast<const uint4 *>(o + (m0 + row) * D + 8 * ch);
-        *reinterpret_cast<uint4 *>(L.xa + row * S256 + 16 * ch) = v;
-    }
-    for (int p = 0; p < 8; ++p) {
-        const int row = 4 * p + (tid >> 6), c4 = tid & 63;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + row < M) v = *reinterpret_cast<const float4 *>(x_cls + (m0 + row) * x_rs + 4 * c4);
-        *reinterpret_cast<float4 *>(xm + row * XM_S + 4 * c4) = v;
+    {
+        const int off[7] = {BO_BO, BO_B1, BO_B2, BO_AB1, BO_AB2, BO_CB1, BO_CB2};
+        const int len[7] = {D, FF, D, HID, HID, HID, HID};
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int i = 0; i < len[k] / THREADS; ++i) L.bias[off[k] + tid + i * THREADS] = in_b[n++];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (tid + i * THREADS < 5 * HID / 8) reinterpret_cast<bf16x8 *>(L.w3)[tid + i * THREADS] = in_w3[i];
+        // the tile's inputs: attention output rows -> xa (bf16), residual CLS rows -> xm (f32); rows past M are zero
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4 *>(L.xa + (8 * p + (tid >> 5)) * S256 + 16 * (tid & 31)) = in_o[p];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<float4 *>(xm + (4 * p + (tid >> 6)) * XM_S + 4 * (tid & 63)) = in_x[p];
     }
     lds_barrier();
-    lds_to_T(L.xa, S256, D, (__bf16 *)S.oT, 0, ld, m0, tid);
+    lds_to_T<D>(L.xa, S256, (__bf16 *)S.oT, 0, steps_ld, step_m0, tid);
 
     // ---- out_proj, dropout, residual add: x_mid = x + dropout(bf16(Wo o + bo))
     {
@@ -268,12 +334,14 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
             constexpr int j = decltype(jc)::value;
             const int mt = 2 * w + j;
             issue(std::integral_constant<int, j + DIST>{});
-            const f32x16 acc = mm16<j % RING>(R, xf, bias_tile(W.bo, 32 * mt, h));
+            const f32x16 acc = mm16<j % RING>(R, xf, bias_tile(L.bias + BO_BO, 32 * mt, h));
             for (int g = 0; g < 4; ++g) {
                 const int f0 = 32 * mt + 8 * g + 4 * h;
                 f32x4 x = *reinterpret_cast<const f32x4 *>(xm + r * XM_S + f0);
-                for (int q = 0; q < 4; ++q)
-                    x[q] += d1.apply((float)(__bf16)acc[4 * g + q], (uint64_t)(m0 + r) * D + f0 + q);
+                float av[4];
+                for (int q = 0; q < 4; ++q) av[q] = (float)(__bf16)acc[4 * g + q];
+                d1.apply4(av, (uint64_t)(m0 + r) * D + f0);
+                for (int q = 0; q < 4; ++q) x[q] += av[q];
                 *reinterpret_cast<f32x4 *>(xm + r * XM_S + f0) = x;
             }
         });
@@ -302,7 +370,7 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
         }
     }
     lds_barrier();
-    lds_to_T(L.xb, S256, D, (__bf16 *)S.h2T, 0, ld, m0, tid);
+    lds_to_T<D>(L.xb, S256, (__bf16 *)S.h2T, 0, steps_ld, step_m0, tid);
 
     // ---- feed-forward: u = dropout(relu(W1 h2 + b1)) in chunks of 128 hidden units, f = W2 u + b2 accumulated per chunk
     {
@@ -310,26 +378,24 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
         load_frags<16>(L.xb, S256, 0, xf, r, h);
         const Drop d2 = drop.site(2), d3 = drop.site(3);
         f32x16 acc2[2];
-        for (int j = 0; j < 2; ++j) acc2[j] = bias_tile(W.b2, 32 * (2 * w + j), h);
+        for (int j = 0; j < 2; ++j) acc2[j] = bias_tile(L.bias + BO_B2, 32 * (2 * w + j), h);
         static_for<0, FF / FC>([&](auto cc) __attribute__((always_inline)) {
             constexpr int c = decltype(cc)::value, u1 = 2 + 2 * c, u2 = 3 + 2 * c;
             const int ht = 4 * c + w;  // hidden tile of this wave
             char *ub = L.u[c & 1];
             issue(std::integral_constant<int, u1 + DIST>{});
-            const f32x16 z = mm16<u1 % RING>(R, xf, bias_tile(W.b1, 32 * ht, h));
+            const f32x16 z = mm16<u1 % RING>(R, xf, bias_tile(L.bias + BO_B1, 32 * ht, h));
             uint32_t bits = 0;
             for (int g = 0; g < 4; ++g) {
                 float v[4];
-                for (int q = 0; q < 4; ++q) {
-                    const int hid = 32 * ht + 8 * g + 4 * h + q;
-                    v[q] = valid ? d2.apply(fmaxf(z[4 * g + q], 0.f), (uint64_t)(m0 + r) * FF + hid) : 0.f;
-                    bits |= (uint32_t)((float)(__bf16)v[q] != 0.f) << (4 * g + q);
-                }
+                for (int q = 0; q < 4; ++q) v[q] = valid ? fmaxf(z[4 * g + q], 0.f) : 0.f;
+                d2.apply4(v, (uint64_t)(m0 + r) * FF + 32 * ht + 8 * g + 4 * h);
+                for (int q = 0; q < 4; ++q) bits |= (uint32_t)((float)(__bf16)v[q] != 0.f) << (4 * g + q);
                 put4(ub, S128, r, 32 * w + 8 * g + 4 * h, v);
             }
             masks_wg[(MT_FFN + ht) * 64 + lane] = (uint16_t)bits;
             lds_barrier();  // chunk c of every wave visible
-            lds_to_T(ub, S128, FC, (__bf16 *)S.uT, FC * c, ld, m0, tid);
+            lds_to_T<FC>(ub, S128, (__bf16 *)S.uT, FC * c, steps_ld, step_m0, tid);
             bf16x8 uf[8];
             load_frags<8>(ub, S128, 0, uf, r, h);
             issue(std::integral_constant<int, u2 + DIST>{});
@@ -345,14 +411,15 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
                 const int f0 = 32 * mt + 8 * g + 4 * h;
                 const f32x4 x = *reinterpret_cast<const f32x4 *>(xm + r * XM_S + f0);
                 float v[4];
-                for (int q = 0; q < 4; ++q)
-                    v[q] = valid ? x[q] + d3.apply((float)(__bf16)acc2[j][4 * g + q], (uint64_t)(m0 + r) * D + f0 + q) : 0.f;
+                for (int q = 0; q < 4; ++q) v[q] = (float)(__bf16)acc2[j][4 * g + q];
+                d3.apply4(v, (uint64_t)(m0 + r) * D + f0);
+                for (int q = 0; q < 4; ++q) v[q] = valid ? x[q] + v[q] : 0.f;
                 put4(L.xa, S256, r, f0, v);
             }
         }
     }
     lds_barrier();
-    lds_to_T(L.xa, S256, D, (__bf16 *)S.featsT, 0, ld, m0, tid);
+    lds_to_T<D>(L.xa, S256, (__bf16 *)S.featsT, 0, steps_ld, step_m0, tid);
     lds_barrier();  // xc (the f32 residual tile) is dead from here on: the heads write bf16 rows into it
 
     // ---- heads: Linear(256 -> 512) + ReLU, Linear(512 -> 512) + ReLU, Linear(512 -> n_out, no bias) on the features in xa
@@ -380,7 +447,7 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
             });
         }
         lds_barrier();
-        lds_to_T(L.xb, S512, HID, h1T, 0, ld, m0, tid);
+        lds_to_T<HID>(L.xb, S512, h1T, 0, steps_ld, step_m0, tid);
         {
             static_for<0, 4>([&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value, u = U0 + 4 + 2 * t;
@@ -405,7 +472,7 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
             });
         }
         lds_barrier();
-        lds_to_T(L.xc, S512, HID, h2T, 0, ld, m0, tid);
+        lds_to_T<HID>(L.xc, S512, h2T, 0, steps_ld, step_m0, tid);
         {   // the output layer (4 logits / 1 value) on the vector ALU: 8 threads per row, 64 inputs each
             const int row = tid >> 3, part = tid & 7;
             float s[N_OUT];
@@ -427,9 +494,9 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
         }
         lds_barrier();  // xb / xc are free again
     };
-    head(std::integral_constant<int, 18>{}, std::integral_constant<int, 4>{}, W.ab1, W.ab2, (const __bf16 *)W.a3, MT_A1, MT_A2,
+    head(std::integral_constant<int, 18>{}, std::integral_constant<int, 4>{}, L.bias + BO_AB1, L.bias + BO_AB2, L.w3, MT_A1, MT_A2,
          (__bf16 *)S.a1T, (__bf16 *)S.a2T, logits);
-    head(std::integral_constant<int, 30>{}, std::integral_constant<int, 1>{}, W.cb1, W.cb2, (const __bf16 *)W.c3, MT_C1, MT_C2,
+    head(std::integral_constant<int, 30>{}, std::integral_constant<int, 1>{}, L.bias + BO_CB1, L.bias + BO_CB2, L.w3 + 4 * HID, MT_C1, MT_C2,
          (__bf16 *)S.c1T, (__bf16 *)S.c2T, values);
 }
 
@@ -447,6 +514,7 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t m0 = (int64_t)blockIdx.x * TB, ld = S.ld;
+    const int steps_ld = (int)(ld >> 4), step_m0 = (int)(m0 >> 4);
     const Drop drop = make_drop(seed, seed_state, p_drop);
     float *const xm = reinterpret_cast<float *>(L.xc);
     const uint16_t *const masks_wg = reinterpret_cast<const uint16_t *>(S.masks) + (int64_t)blockIdx.x * N_MASK_TILES * 64;
@@ -471,14 +539,36 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
         }
         sched_fence();
     };
+    // ---- prologue: all of its loads first, then the ring's first two units, then the LDS writes (see k_tail_fwd)
+    uint4 in_m[3];
+    bf16x8 in_w3[2];
+    float4 in_dl = make_float4(0.f, 0.f, 0.f, 0.f);
+    float in_dv = 0.f;
+    {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) in_m[i] = reinterpret_cast<const uint4 *>(masks_wg)[tid + i * THREADS];  // 96 * 64 * 2 B = 768 vectors
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * THREADS;
+            in_w3[i] = e < 4 * HID / 8 ? reinterpret_cast<const bf16x8 *>(WT.a3)[e]
+                                       : reinterpret_cast<const bf16x8 *>(WT.c3)[e < 5 * HID / 8 ? e - 4 * HID / 8 : 0];
+        }
+        if (tid < 32 && m0 + tid < M) {
+            in_dl = reinterpret_cast<const float4 *>(dlogits)[m0 + tid];
+            in_dv = dvalues[m0 + tid];
+        }
+    }
+    sched_fence();
     issue(std::integral_constant<int, 0>{});
     issue(std::integral_constant<int, 1>{});
-
+#pragma unroll
+    for (int i = 0; i < 3; ++i) reinterpret_cast<uint4 *>(L.masks)[tid + i * THREADS] = in_m[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        if (tid + i * THREADS < 5 * HID / 8) reinterpret_cast<bf16x8 *>(L.w3)[tid + i * THREADS] = in_w3[i];
     if (tid < 32) {
-        const bool ok = m0 + tid < M;
-        const float4 v = ok ? reinterpret_cast<const float4 *>(dlogits)[m0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
-        L.dl[tid][0] = v.x; L.dl[tid][1] = v.y; L.dl[tid][2] = v.z; L.dl[tid][3] = v.w;
-        L.dl[tid][4] = ok ? dvalues[m0 + tid] : 0.f;
+        L.dl[tid][0] = in_dl.x; L.dl[tid][1] = in_dl.y; L.dl[tid][2] = in_dl.z; L.dl[tid][3] = in_dl.w;
+        L.dl[tid][4] = in_dv;
     }
     lds_barrier();
 
@@ -494,7 +584,7 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
         }
         for (int t = 0; t < 4; ++t) {
             const int mt = 4 * w + t;
-            const uint32_t bits = masks_wg[(mt2 + mt) * 64 + lane];
+            const uint32_t bits = L.masks[(mt2 + mt) * 64 + lane];
             float dlr[N_OUT];
             for (int oo = 0; oo < N_OUT; ++oo) dlr[oo] = (float)(__bf16)L.dl[r][dl_col0 + oo];
             for (int g = 0; g < 4; ++g) {
@@ -509,7 +599,7 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
             }
         }
         lds_barrier();
-        lds_to_T(L.xa, S512, HID, d2T, 0, ld, m0, tid);
+        lds_to_T<HID>(L.xa, S512, d2T, 0, steps_ld, step_m0, tid);
         {   // d a1 = (W2^T d a2) where a1 > 0 -> xb
             static_for<0, 4>([&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value, u = U0 + 2 * t;
@@ -521,7 +611,7 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
                 issue(std::integral_constant<int, u + 1 + DIST>{});
                 load_frags<16>(L.xa, S512, 256, af, r, h);
                 acc = mm16<(u + 1) % RING>(R, af, acc);
-                const uint32_t bits = masks_wg[(mt1 + mt) * 64 + lane];
+                const uint32_t bits = L.masks[(mt1 + mt) * 64 + lane];
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
                     for (int q = 0; q < 4; ++q) v[q] = ((bits >> (4 * g + q)) & 1u) ? acc[4 * g + q] : 0.f;
@@ -530,7 +620,7 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
             });
         }
         lds_barrier();
-        lds_to_T(L.xb, S512, HID, d1T, 0, ld, m0, tid);
+        lds_to_T<HID>(L.xb, S512, d1T, 0, steps_ld, step_m0, tid);
         {   // d features += W1^T d a1
             static_for<0, 2>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value, u = U0 + 8 + 2 * j;
@@ -545,9 +635,9 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
         }
         lds_barrier();  // xa / xb are free again (every wave holds its fragments in registers)
     };
-    head(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, (const __bf16 *)WT.a3, 0, MT_A1, MT_A2, (__bf16 *)G.dlT,
-         (__bf16 *)G.da2T, (__bf16 *)G.da1T);
-    head(std::integral_constant<int, 12>{}, std::integral_constant<int, 1>{}, (const __bf16 *)WT.c3, 4, MT_C1, MT_C2, (__bf16 *)G.dvT,
+    head(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, L.w3, 0, MT_A1, MT_A2, (__bf16 *)G.dlT, (__bf16 *)G.da2T,
+         (__bf16 *)G.da1T);
+    head(std::integral_constant<int, 12>{}, std::integral_constant<int, 1>{}, L.w3 + 4 * HID, 4, MT_C1, MT_C2, (__bf16 *)G.dvT,
          (__bf16 *)G.dc2T, (__bf16 *)G.dc1T);
 
     // ---- features = bf16(x_mid + dropout(f)): g = bf16(d features) flows into the residual (-> xm, f32) and, masked, into f (-> xa)
@@ -559,17 +649,15 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
                 const int f0 = 32 * mt + 8 * g + 4 * h;
                 f32x4 gx;
                 float v[4];
-                for (int q = 0; q < 4; ++q) {
-                    gx[q] = (float)(__bf16)dfeat[j][4 * g + q];
-                    v[q] = d3.apply(gx[q], (uint64_t)(m0 + r) * D + f0 + q);
-                }
+                for (int q = 0; q < 4; ++q) v[q] = gx[q] = (float)(__bf16)dfeat[j][4 * g + q];
+                d3.apply4(v, (uint64_t)(m0 + r) * D + f0);
                 *reinterpret_cast<f32x4 *>(xm + r * XM_S + f0) = gx;
                 put4(L.xa, S256, r, f0, v);
             }
         }
     }
     lds_barrier();
-    lds_to_T(L.xa, S256, D, (__bf16 *)G.df2T, 0, ld, m0, tid);
+    lds_to_T<D>(L.xa, S256, (__bf16 *)G.df2T, 0, steps_ld, step_m0, tid);
 
     // ---- feed-forward backward, in the forward's chunks: dz = (W2^T df) * [u != 0] / keep;  d h2 += W1^T dz
     {
@@ -582,14 +670,14 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
             char *ub = L.u[c & 1];
             issue(std::integral_constant<int, u1 + DIST>{});
             const f32x16 du = mm16<u1 % RING>(R, xf, zero_tile());
-            const uint32_t bits = masks_wg[(MT_FFN + ht) * 64 + lane];
+            const uint32_t bits = L.masks[(MT_FFN + ht) * 64 + lane];
             for (int g = 0; g < 4; ++g) {
                 float v[4];
                 for (int q = 0; q < 4; ++q) v[q] = ((bits >> (4 * g + q)) & 1u) ? du[4 * g + q] * drop.inv_keep : 0.f;
                 put4(ub, S128, r, 32 * w + 8 * g + 4 * h, v);
             }
             lds_barrier();
-            lds_to_T(ub, S128, FC, (__bf16 *)G.dzT, FC * c, ld, m0, tid);
+            lds_to_T<FC>(ub, S128, (__bf16 *)G.dzT, FC * c, steps_ld, step_m0, tid);
             bf16x8 uf[8];
             load_frags<8>(ub, S128, 0, uf, r, h);
             issue(std::integral_constant<int, u2 + DIST>{});
@@ -613,12 +701,24 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
         const float4 gm = reinterpret_cast<const float4 *>(WT.ln_g)[lane];
         const float gg[4] = {gm.x, gm.y, gm.z, gm.w};
         float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+        // the eight rows of this wave: saved residual rows and statistics fetched up front (eight independent loads in flight
+        // instead of one exposed round trip per row)
+        float4 vrow[8];
+        float mrow[8], rrow[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * w + i;
+            const int64_t m = m0 + row < M ? m0 + row : M - 1;  // clamped: loads stay in bounds; rows past M carry zero gradients
+            vrow[i] = reinterpret_cast<const float4 *>(S.x_mid + m * D)[lane];
+            mrow[i] = S.mean[m];
+            rrow[i] = S.rstd[m];
+        }
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = 8 * w + i;
             const bool ok = m0 + row < M;
-            const int64_t m = ok ? m0 + row : M - 1;  // clamped: loads stay in bounds; rows past M carry zero gradients
-            const float4 v = reinterpret_cast<const float4 *>(S.x_mid + m * D)[lane];
-            const float mean = S.mean[m], rstd = S.rstd[m];
+            const float4 v = vrow[i];
+            const float mean = mrow[i], rstd = rrow[i];
             const bf16x4 ghb = *reinterpret_cast<const bf16x4 *>(L.xb + row * S256 + 8 * lane);
             const float4 gx = *reinterpret_cast<const float4 *>(xm + row * XM_S + 4 * lane);
             const float xh[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
@@ -635,7 +735,8 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
             float ov[4] = {gx.x, gx.y, gx.z, gx.w};
             for (int q = 0; q < 4; ++q) ov[q] += rstd * (dxh[q] - c1 - xh[q] * c2);
             if (ok) reinterpret_cast<float4 *>(dx_cls + (m0 + row) * D)[lane] = make_float4(ov[0], ov[1], ov[2], ov[3]);
-            for (int q = 0; q < 4; ++q) ov[q] = ok ? d1.apply(ov[q], (uint64_t)(m0 + row) * D + 4 * lane + q) : 0.f;
+            d1.apply4(ov, (uint64_t)(m0 + row) * D + 4 * lane);
+            for (int q = 0; q < 4; ++q) ov[q] = ok ? ov[q] : 0.f;
             put4(L.xa, S256, row, 4 * lane, ov);
         }
         for (int q = 0; q < 4; ++q) {
@@ -648,7 +749,7 @@ k_tail_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues,
         const int which = c / D, col = c - which * D;
         G.ln_partial[(int64_t)blockIdx.x * 2 * D + c] = L.red[0][which][col] + L.red[1][which][col] + L.red[2][which][col] + L.red[3][which][col];
     }
-    lds_to_T(L.xa, S256, D, (__bf16 *)G.daoT, 0, ld, m0, tid);
+    lds_to_T<D>(L.xa, S256, (__bf16 *)G.daoT, 0, steps_ld, step_m0, tid);
 
     // ---- d o = Wo^T d(out_proj output), bf16 rows for the attention backward
     {

@@ -5,6 +5,8 @@ import copy
 import numpy as np
 import pytest
 import torch
+
+from src.g2048 import native as nv
 import torch.nn as nn
 from torch.amp import GradScaler
 

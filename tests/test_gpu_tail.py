@@ -42,22 +42,25 @@ def _plan(P, p_drop, cache=None):
 
 
 def _keep(seed, site, rows, cols, p):
-    """numpy replica of the kernels' dropout hash (keep_elem / Drop::site in csrc/g2048_tail.hip) -> bool [rows, cols]."""
+    """numpy replica of the kernels' dropout decision (Drop::site / Drop::apply4 in csrc/g2048_tail.hip: one hash per PAIR of
+    consecutive elements, its 16-bit halves against the threshold at 16-bit resolution) -> bool [rows, cols]."""
     if p == 0:
         return np.ones((rows, cols), bool)
     M32 = np.uint64(0xFFFFFFFF)
     s0 = np.uint64((int(seed) & 0xFFFFFFFF) + site * 0x632BE5AB) & M32
     s1 = np.uint64((int(seed) >> 32) ^ ((site * 0x7F4A7C15) & 0xFFFFFFFF)) & M32
-    thr = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
+    thr16 = np.uint64(int(np.float32(p) * np.float32(16777216.0)) >> 8)
     idx = np.arange(rows * cols, dtype=np.uint64)
-    x = ((idx & M32) * np.uint64(0x9E3779B1) & M32) ^ s0
-    x ^= (((idx >> np.uint64(32)) * np.uint64(0x85EBCA77)) + s1) & M32
+    pair = idx >> np.uint64(1)
+    x = ((pair & M32) * np.uint64(0x9E3779B1) & M32) ^ s0
+    x ^= (((pair >> np.uint64(32)) * np.uint64(0x85EBCA77)) + s1) & M32
     x ^= x >> np.uint64(16)
     x = x * np.uint64(0x7FEB352D) & M32
     x ^= x >> np.uint64(15)
     x = x * np.uint64(0x846CA68B) & M32
     x ^= x >> np.uint64(16)
-    return ((x >> np.uint64(8)) >= thr).reshape(rows, cols)
+    half = np.where((idx & np.uint64(1)) == 0, x & np.uint64(0xFFFF), x >> np.uint64(16))
+    return (half >= thr16).reshape(rows, cols)
 
 
 def _reference(P, o, x, p, seed, buf):
@@ -145,8 +148,9 @@ def test_dweight_t_matches_matmul(dev):
         torch.testing.assert_close(dw.sum(0), w_ref, rtol=1e-4, atol=1e-3)
         if db is not None:
             torch.testing.assert_close(db.sum(0), b_ref, rtol=1e-4, atol=1e-3)
-    nv.dweight_t(jobs[:1], ld, 96, 2)  # a shorter row range in two slices of 3 k-steps each: the remainder loop
-    torch.testing.assert_close(jobs[0][2][:2].sum(0), nv.unpack_fragments(jobs[0][0], 64, ld)[:, :96].float()
+    dw2 = torch.full((2, 64, 64), float("nan"), device=dev)
+    nv.dweight_t([(jobs[0][0], jobs[0][1], dw2, None)], ld, 96, 2)  # a shorter row range, two slices of 3 k-steps: the remainder loop
+    torch.testing.assert_close(dw2.sum(0), nv.unpack_fragments(jobs[0][0], 64, ld)[:, :96].float()
                                @ nv.unpack_fragments(jobs[0][1], 64, ld)[:, :96].float().t(), rtol=1e-4, atol=1e-3)
     with pytest.raises(nv.NativeError):
         nv.dweight_t(jobs, ld, 250, slices)  # rows not a multiple of 16 * slices
