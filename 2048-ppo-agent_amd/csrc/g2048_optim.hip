@@ -5,7 +5,9 @@
 // Layout: gradients and both moments live in flat f32 buffers (the gradient buffer is the all-reduce bucket of a
 // multi-GPU run); the parameters stay where the module owns them.  A chunk table cuts every parameter tensor into pieces of
 // at most OPT_CHUNK elements; workgroup b owns chunk b in both kernels, so the summation order of the norm is fixed.
-//   k_opt_sqnorm : partial[b] = sum over chunk b of g^2 (raw, still loss-scaled gradients)
+//   k_opt_sqnorm : partial[b] = sum over chunk b of (g * inv_scale)^2 (the UNSCALED gradients, as clip_grad_norm_ sees them after
+//                  scaler.unscale_: summing the squares of the still loss-scaled values overflowed f32 once the scale passed ~2^60,
+//                  long before torch's own element-wise inf check would skip a step)
 //   k_opt_adamw  : every workgroup adds the partials in the same order -> total norm, found_inf, clip factor; then
 //                  g' = (g * inv_scale) * clip;  p -= lr*wd*p;  m = lerp(m, g', 1-b1);  v = b2*v + (1-b2)*g'^2;
 //                  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)                      (torch's fused AdamW arithmetic)
@@ -48,11 +50,12 @@ struct Derived { float step_size, inv_bc2_sqrt, lr_wd, w1, b2, w2, eps, pad; };
 
 __global__ void __launch_bounds__(OPT_THREADS)
 k_opt_sqnorm(const g2048_opt_chunk *__restrict__ chunks, const float *__restrict__ grads, float *__restrict__ partial, StepArgs A,
-             int n_groups, const float *__restrict__ steps, Derived *__restrict__ derived) {
+             int n_groups, const float *__restrict__ steps, Derived *__restrict__ derived, const float *__restrict__ scale) {
     __shared__ float lds[OPT_THREADS / 64];
     if (blockIdx.x == 0 && threadIdx.x < n_groups) {
         const g2048_opt_group G = A.groups[threadIdx.x];
-        const double t = (double)steps[0] + 1.0;
+        const double t = (double)steps[0] + 1.0;  // (all step counts are equal: every parameter steps on every non-skipped call;
+                                                    //  FlatAdamWStep.adopt_state asserts it for loaded states)
         const double bc1 = 1.0 - pow(G.beta1, t), bc2 = 1.0 - pow(G.beta2, t);
         Derived d;
         // hyper-parameters arrive as f64 (what torch.optim holds) and are rounded once, after the f64 arithmetic on them
@@ -68,13 +71,15 @@ k_opt_sqnorm(const g2048_opt_chunk *__restrict__ chunks, const float *__restrict
     }
     const g2048_opt_chunk c = chunks[blockIdx.x];
     const float *g = grads + c.offset;
+    const float inv_scale = scale ? (float)(1.0 / (double)*scale) : 1.f;  // scaler.unscale_: grads *= scale.double().reciprocal().float()
     float s = 0.f;
     for (int i = threadIdx.x * OPT_VEC; i < c.n; i += OPT_THREADS * OPT_VEC) {
         if (i + OPT_VEC <= c.n) {
-            const float4 v = *reinterpret_cast<const float4 *>(g + i);
+            float4 v = *reinterpret_cast<const float4 *>(g + i);
+            v.x *= inv_scale; v.y *= inv_scale; v.z *= inv_scale; v.w *= inv_scale;
             s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         } else {
-            for (int k = i; k < c.n; ++k) s += g[k] * g[k];
+            for (int k = i; k < c.n; ++k) s += (g[k] * inv_scale) * (g[k] * inv_scale);
         }
     }
     s = block_sum(s, lds);
@@ -173,8 +178,8 @@ k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const floa
     if (threadIdx.x == 0) {
         const float sc = scale ? *scale : 1.f;
         const float inv_scale = (float)(1.0 / (double)sc);  // scaler.unscale_: grads *= scale.double().reciprocal().float()
-        // the norm of the unscaled gradients; non-finite anywhere makes the total non-finite
-        const float norm = sqrtf(total) * inv_scale;
+        // the norm of the unscaled gradients (k_opt_sqnorm squared g * inv_scale); non-finite anywhere makes the total non-finite
+        const float norm = sqrtf(total);
         float clip = 1.f;
         if (max_grad_norm > 0.f) {
             clip = max_grad_norm / (norm + 1e-6f);  // torch.nn.utils.clip_grad_norm_
@@ -257,8 +262,7 @@ k_opt_finish(const float *__restrict__ partial, int n_chunks, float growth, floa
         for (int i = threadIdx.x; i < n_steps; i += OPT_THREADS) steps[i] += 1.f;  // one count per parameter, as torch keeps them
     if (threadIdx.x == 0) {
         if (info) {
-            const float sc = scale ? *scale : 1.f;
-            info[0] = sqrtf(total) * (float)(1.0 / (double)sc);  // gradient norm before clipping (what clip_grad_norm_ returns)
+            info[0] = sqrtf(total);  // gradient norm (unscaled) before clipping: what clip_grad_norm_ returns
             info[1] = found_inf ? 1.f : 0.f;
         }
         if (scale) {
@@ -294,7 +298,7 @@ extern "C" int g2048_opt_step(const g2048_opt_chunk *chunks, int n_chunks, const
     float *partial = workspace;
     Derived *derived = reinterpret_cast<Derived *>(workspace + ((n_chunks + 3) & ~3));
     hipLaunchKernelGGL(k_opt_sqnorm, dim3((unsigned)n_chunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, chunks, grads, partial, A,
-                       n_groups, steps, derived);
+                       n_groups, steps, derived, scale);
     hipLaunchKernelGGL(k_opt_adamw, dim3((unsigned)n_chunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, chunks, n_chunks, grads,
                        exp_avg, exp_avg_sq, partial, derived, max_grad_norm, scale);
     hipLaunchKernelGGL(k_opt_finish, dim3(1), dim3(OPT_THREADS), 0, (hipStream_t)stream, partial, n_chunks, growth, backoff,

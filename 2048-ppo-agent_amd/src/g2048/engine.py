@@ -93,6 +93,24 @@ class FixedTrajectory:
         length = torch.where(prev >= 0, t - prev, t + 1 + self.ep_len_before[None, :])
         return length[done]
 
+    def finished_episode_max_rewards(self, carry: Optional[torch.Tensor] = None):
+        """-> (f32 [n], f32 [B]): the largest single-step reward of every episode that ended inside this rollout, in the order of
+        ``finished_episode_lengths`` (the reference's per-episode "episode reward" statistic, src/ppo/ppo_trainer.py:204-215), and
+        the running maximum of each lane's unfinished episode to hand to the next rollout.  ``carry``: that running maximum from
+        the previous rollout of the same lanes (None: episodes start here)."""
+        done = self.terms.bool()  # [T, B]
+        T, B = done.shape
+        seg = torch.cumsum(done.to(torch.int64), dim=0) - done.to(torch.int64)  # terminations before row t = its episode's index
+        lane = torch.arange(B, device=done.device, dtype=torch.int64)[None, :]
+        key = (seg * B + lane).reshape(-1)
+        best = torch.full(((T + 1) * B,), float("-inf"), dtype=torch.float32, device=done.device)
+        best = best.scatter_reduce(0, key, self.rewards.reshape(-1).float(), reduce="amax").view(T + 1, B)
+        if carry is not None:
+            best[0] = torch.maximum(best[0], carry.to(best.dtype))
+        vals = best.reshape(-1)[key].view(T, B)[done]
+        n_done = done.sum(dim=0)  # the unfinished episode of a lane is its segment number n_done (-inf when nothing of it ran yet)
+        return vals, best.gather(0, n_done[None, :]).squeeze(0)
+
 
 class RolloutEngine:
     """One shard of a lock-step batch: envs [env0, env0 + B) of B_total, on one GPU."""

@@ -78,6 +78,11 @@ class FlatAdamWStep:
                 elif not (torch.is_tensor(t) and t.data_ptr() == self.steps[i].data_ptr()):
                     self.steps[i] = float(t)
             st[p] = {"step": self.steps[i], "exp_avg": self.m_views[i], "exp_avg_sq": self.v_views[i]}
+        # the kernel derives the bias corrections of every group from steps[0]: a loaded state whose parameters disagree on the
+        # step count (parameters frozen for part of a run under a plain AdamW) cannot be continued by this step
+        if self.steps.numel() and float(self.steps.min()) != float(self.steps.max()):
+            raise ValueError("FlatAdamWStep: the optimizer state holds different step counts per parameter "
+                             f"({float(self.steps.min()):.0f}..{float(self.steps.max()):.0f}); g2048_opt_step keeps one count for all")
 
     def adopt_shadows(self, shadows):
         """Keep bf16 shadow copies of parameters up to date from inside the optimiser kernel.  ``shadows``: objects with
@@ -97,24 +102,29 @@ class FlatAdamWStep:
             self._table_key = None  # rebuild the chunk table with the shadow pointers
         return len(self._shadows)
 
-    def _chunk_table(self):
-        key = tuple(p.data_ptr() for p in self.params) + tuple(id(sh) for sh in self._shadows)
+    def _chunk_table(self, skip=()):
+        key = tuple(p.data_ptr() for p in self.params) + tuple(id(sh) for sh in self._shadows) + ("skip",) + tuple(skip)
         if key != self._table_key:  # a parameter was re-allocated (module.to(), load with assign=True, ...) or shadows joined
             shadow_of = {}
             for sh in self._shadows:
                 for i, p in enumerate(sh.params):
                     shadow_of[id(p)] = (sh.views[i], sh.tviews.get(i), getattr(sh, "pviews", {}).get(i),
                                         getattr(sh, "ptviews", {}).get(i))
-            self._table = nv.opt_chunk_table(self.params, self.offsets, self.group_of, self.device, shadow_of)
+            keep = [i for i in range(len(self.params)) if i not in set(skip)]
+            self._table = nv.opt_chunk_table([self.params[i] for i in keep], [self.offsets[i] for i in keep],
+                                             [self.group_of[i] for i in keep], self.device, shadow_of)
             self._n_chunks = self._table.numel() // nv.OPT_CHUNK_BYTES
             self._ws = nv.opt_workspace(self._n_chunks, self.device)
             self._table_key = key
         return self._table
 
     # ------------------------------------------------------------------ the step
-    def step(self, max_grad_norm, scaler=None):
-        """Gradients are read from ``self.grad`` (bind ``p.grad`` to ``grad_views`` or copy into them first)."""
-        table = self._chunk_table()
+    def step(self, max_grad_norm, scaler=None, skip=()):
+        """Gradients are read from ``self.grad`` (bind ``p.grad`` to ``grad_views`` or copy into them first).
+        ``skip``: indices (into ``self.params``) of parameters that received NO gradient this step: like torch.optim.AdamW they are
+        left alone entirely -- no weight decay, no moment update, out of the gradient norm (their slice of ``self.grad`` is not
+        read).  Their step counter still advances with the others (the kernel keeps one count for all parameters)."""
+        table = self._chunk_table(tuple(sorted(skip)))
         groups = []
         for g in self.optimizer.param_groups:
             b1, b2 = g["betas"]
@@ -126,12 +136,16 @@ class FlatAdamWStep:
                 scaler._lazy_init_scale_growth_tracker(self.device)
             scale, tracker = scaler._scale, scaler._growth_tracker
             growth, backoff, interval = scaler.get_growth_factor(), scaler.get_backoff_factor(), scaler.get_growth_interval()
+        # shadows that were current BEFORE this step stay current through it (the kernel rewrites them with the parameters, or
+        # leaves both untouched on a skipped step); one that was stale (a parameter changed behind the optimiser's back) stays
+        # stale, so that its next use copies for real
+        was_current = [sh.key == sh.current_key() for sh in self._shadows]
         nv.opt_step(table, self._n_chunks, self.grad, self.exp_avg, self.exp_avg_sq, groups, max_grad_norm, self.steps, scale,
                     tracker, growth, backoff, interval, self._ws, self.info)
         # the kernel wrote the parameters through raw pointers: tell autograd's version counters, which is what everything
         # that caches derived weights keys on (the bf16 shadows of the update path, the packed weights of the fused rollout
         # encoder, torch's own saved-tensor checks).  No launch.
         torch.autograd.graph.increment_version(self.params)
-        for sh in self._shadows:  # the kernel rewrote them together with the parameters: their key follows the new versions
-            sh.key = sh.current_key()
+        for sh, ok in zip(self._shadows, was_current):  # rewritten together with the parameters: the key follows the new versions
+            sh.key = sh.current_key() if ok else None
         self.optimizer._opt_called = True  # the LR scheduler checks that a step preceded scheduler.step()

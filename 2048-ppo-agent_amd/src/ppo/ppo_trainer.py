@@ -177,6 +177,14 @@ class _GraphedFwdBwd:
 
     def replay(self):
         """Replay on whatever ``self.static`` holds (the minibatch gather kernel writes there directly)."""
+        # A replay runs no Python: shadows that the optimiser kernel maintains have no cast kernel inside the graph.  If somebody
+        # else changed a parameter since (agent.load_state_dict, a manual edit, a broadcast), refresh them eagerly first (host-side
+        # key comparison only; no launch in the normal case).
+        fs = self.tr._flat_step
+        if fs is not None:
+            for sh in fs._shadows:
+                if sh.key != sh.current_key():
+                    sh()
         self.graph.replay()
         for p, g in zip(self.tr.agent.parameters(), self.grads):  # an eager step in between may have re-pointed them
             p.grad = g
@@ -303,6 +311,7 @@ class PPOTrainer:
         self.last_save_timestep = 0
         self.load_checkpoint_path = None
         self.last_rollout_stats: Dict[str, float] = {}
+        self._fixed_reward_carry = None  # fixed_horizon mode: running max reward of every lane's unfinished episode
 
     @property
     def rollout_graph_fallback(self):
@@ -335,9 +344,11 @@ class PPOTrainer:
 
     def _collect_grads(self, point_grads: bool = True):
         src, dst = [], []
-        for p, v in zip(self._params, self._flat_views):
+        self._no_grad = []  # indices of parameters without a gradient this step: the optimiser leaves them alone, as torch's does
+        for i, (p, v) in enumerate(zip(self._params, self._flat_views)):
             if p.grad is None:
                 v.zero_()
+                self._no_grad.append(i)
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
@@ -411,7 +422,12 @@ class PPOTrainer:
                     lens = traj.finished_episode_lengths()
                     total_episodes += int(lens.numel())
                     ep_len.append(lens)
-                    ep_rew.append(traj.rewards.max(dim=0).values)  # largest single-step reward of every lane's rows
+                    # per FINISHED episode, like the lengths (and like the reference's statistic): the largest single-step reward
+                    # of the episode, carried across rollouts for episodes that span several of them
+                    vals, self._fixed_reward_carry = traj.finished_episode_max_rewards(
+                        self._fixed_reward_carry if (self._fixed_reward_carry is not None
+                                                     and self._fixed_reward_carry.shape[0] == traj.B) else None)
+                    ep_rew.append(vals)
             self._finish_collect(ep_rew, ep_len, total_episodes)
             return
         with torch.no_grad():
@@ -624,7 +640,8 @@ class PPOTrainer:
                 self._allreduce_grads(collective=not (graphed is not None and graphed.allreduce_captured))
                 if self._flat_step is not None:
                     self._flat_step.adopt_shadows(list(Bf16Shadow._live))  # (no-op once they are adopted)
-                    self._flat_step.step(self.max_grad_norm, self.scaler if self.use_amp else None)
+                    self._flat_step.step(self.max_grad_norm, self.scaler if self.use_amp else None,
+                                         skip=getattr(self, "_no_grad", ()))
                 elif self.use_amp:
                     self.scaler.unscale_(self.optimizer)
                     torch.nn.utils.clip_grad_norm_(self.agent.parameters(), self.max_grad_norm)

@@ -320,3 +320,28 @@ def test_grad_sink_equals_per_parameter_reductions(dev, tmp_path, monkeypatch):
     # and the bucket holds exactly these values (what the optimiser kernel reads)
     for p, v in zip(tr_s._params, tr_s._flat_views):
         assert p.grad.data_ptr() == v.data_ptr()
+
+
+def test_flat_step_leaves_parameters_without_gradient_alone(dev):
+    """A parameter that received no gradient (``skip``) is not decayed, its moments stay untouched and it does not enter the
+    gradient norm -- what torch.optim.AdamW does with ``p.grad is None`` -- while the others step exactly as without it."""
+    torch.manual_seed(2)
+    ps = [nn.Parameter(torch.randn(300, 256, device=dev)), nn.Parameter(torch.randn(77, device=dev)),
+          nn.Parameter(torch.randn(64, 32, device=dev))]
+    ref = [nn.Parameter(p.detach().clone()) for p in ps]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.1)
+    opt, opt_ref = torch.optim.AdamW(ps, **kw), torch.optim.AdamW(ref, **kw)
+    fs = FlatAdamWStep(opt, dev)
+    for step in range(3):
+        g0, g2 = torch.randn_like(ps[0]), torch.randn_like(ps[2])
+        fs.grad_views[0].copy_(g0)
+        fs.grad_views[1].fill_(float("nan"))  # never read: the parameter is skipped
+        fs.grad_views[2].copy_(g2)
+        ref[0].grad, ref[1].grad, ref[2].grad = g0.clone(), None, g2.clone()
+        torch.nn.utils.clip_grad_norm_([ref[0], ref[2]], 0.5)
+        opt_ref.step()
+        fs.step(0.5, None, skip=(1,))
+        assert float(fs.info[1]) == 0.0  # the NaN slice did not reach the norm
+    torch.testing.assert_close(ps[0].detach(), ref[0].detach(), rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(ps[2].detach(), ref[2].detach(), rtol=2e-6, atol=2e-6)
+    assert torch.equal(ps[1].detach(), ref[1].detach()) and not bool(fs.m_views[1].any()) and not bool(fs.v_views[1].any())

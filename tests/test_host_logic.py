@@ -339,3 +339,37 @@ def test_rollout_precision_default():
     assert r(None, None, {}) is False and r(None, "float16", {}) is False
     assert r(False, "bfloat16", {}) is False and r(True, None, {"G2048_ROLLOUT_FP32": "1"}) is True
     assert r(None, "bfloat16", {"G2048_ROLLOUT_AMP": "0"}) is False and r(None, None, {"G2048_ROLLOUT_AMP": "1"}) is True
+
+
+def test_fixed_horizon_per_episode_reward_statistic():
+    """FixedTrajectory.finished_episode_max_rewards: one value per FINISHED episode (aligned with finished_episode_lengths), the
+    largest single-step reward of that episode, carried across rollouts for episodes that span several of them -- against a
+    per-lane Python walk over two consecutive windows."""
+    from src.g2048.engine import FixedTrajectory
+
+    g = torch.Generator().manual_seed(4)
+    T, B = 9, 6
+
+    def window():
+        rewards = torch.randint(0, 50, (T, B), generator=g).float()
+        done = torch.rand(T, B, generator=g) < 0.3
+        meta = (done.to(torch.uint8) << 6)
+        z = torch.zeros
+        return FixedTrajectory(boards=z(T, B, 16, dtype=torch.uint8), meta=meta, rewards=rewards, log_probs=z(T, B), values=z(T, B),
+                               final_boards=z(B, 16, dtype=torch.uint8), final_masks=z(B, dtype=torch.uint8),
+                               ep_len=z(B, dtype=torch.int32), ep_len_before=z(B, dtype=torch.int32), T=T, B=B), rewards, done
+
+    run = [float("-inf")] * B  # the walk's running maxima
+    carry = None
+    for _ in range(2):
+        traj, rewards, done = window()
+        want = []
+        for t in range(T):  # row-major over (t, lane): the order of boolean indexing with the [T, B] mask
+            for b in range(B):
+                run[b] = max(run[b], float(rewards[t, b]))
+                if bool(done[t, b]):
+                    want.append(run[b])
+                    run[b] = float("-inf")
+        vals, carry = traj.finished_episode_max_rewards(carry)
+        assert vals.tolist() == want and vals.numel() == traj.finished_episode_lengths().numel()
+        assert carry.tolist() == run
