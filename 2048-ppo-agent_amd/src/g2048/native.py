@@ -77,8 +77,6 @@ SIGNATURES = {
     "g2048_cls_tail_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_cls_tail_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_dweight_t": [_vp, _i32, _i64, _i64, _i32, _vp],
-    "g2048_block_bits_bytes": [_i64],
-    "g2048_block_fwd": [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp],
     "g2048_opt_workspace_floats": [_i32],
     "g2048_opt_step": [_vp, _i32, _vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _i32, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp, _vp],
 }
@@ -104,7 +102,7 @@ def load() -> C.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
-            fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_workspace_bytes", "_partial_rows", "_mask_bytes", "_bits_bytes")) else C.c_int
+            fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_workspace_bytes", "_partial_rows", "_mask_bytes")) else C.c_int
         if lib.g2048_abi_version() != 2:
             raise NativeError("libg2048.so ABI version mismatch")
         _lib = lib
@@ -777,36 +775,3 @@ def dweight_t(jobs, ld: int, m: int, slices: int):
     arr = (DwJob * len(recs))(*recs)
     _check(load().g2048_dweight_t(C.cast(arr, _vp), len(recs), int(ld), int(m), int(slices), _stream()), "g2048_dweight_t")
 
-
-# ---------------------------------------------------------------------------------------------------------------------
-# the second half of a full encoder layer (csrc/g2048_block.hip)
-# ---------------------------------------------------------------------------------------------------------------------
-class BlockWeights(C.Structure):
-    _fields_ = [(n, _vp) for n in ("wo", "w1", "w2", "bo", "b1", "b2", "ln2_g", "ln2_b", "lnn_g", "lnn_b")]
-
-
-class BlockSaved(C.Structure):
-    _fields_ = [(n, _vp) for n in ("x_mid", "mean2", "rstd2", "h2", "u", "bits", "x_out", "mean_n", "rstd_n", "h_next")]
-
-
-_BLOCK_F32 = {n: f32 for n in ("bo", "b1", "b2", "ln2_g", "ln2_b", "lnn_g", "lnn_b")}
-
-
-def block_weights(tensors: dict) -> BlockWeights:
-    """fragment-packed bf16 wo / w1 / w2 + f32 biases and LayerNorm parameters by field name (the caller keeps them alive)."""
-    return _ptr_struct(BlockWeights, tensors, _BLOCK_F32)
-
-
-def block_fwd(a, x, W: BlockWeights, M: int, eps2: float, eps_next: float, p_drop: float, seeds, seed_state: int = 0):
-    """a bf16 [M, 256], x f32 [M, 256] -> dict of what g2048_block_fwd wrote (x_mid, mean2, rstd2, h2, u, bits, x_out, mean_n,
-    rstd_n, h_next)."""
-    dev, bf = a.device, torch.bfloat16
-    e = lambda *shape, dtype=bf: torch.empty(shape, dtype=dtype, device=dev)
-    out = dict(x_mid=e(M, 256, dtype=f32), mean2=e(M, dtype=f32), rstd2=e(M, dtype=f32), h2=e(M, 256), u=e(M, 1024),
-               bits=e(load().g2048_block_bits_bytes(M), dtype=u8), x_out=e(M, 256, dtype=f32), mean_n=e(M, dtype=f32),
-               rstd_n=e(M, dtype=f32), h_next=e(M, 256))
-    S = BlockSaved(*[out[n].data_ptr() for n, _ in BlockSaved._fields_])
-    _check(load().g2048_block_fwd(_dev(a, bf, 256 * M, "a"), _dev(x, f32, 256 * M, "x"), C.byref(W), C.byref(S), M, float(eps2),
-                                  float(eps_next), float(p_drop), int(seeds[0]), int(seeds[1]), int(seeds[2]), seed_state or None,
-                                  _stream()), "g2048_block_fwd")
-    return out

@@ -1023,112 +1023,3 @@ class _ClsTailHeads(torch.autograd.Function):
             return (do_out, dx_out, None) + (None,) * len(TAIL_PARAM_ORDER)
         return (do_out, dx_out, None) + tuple(grads[k] for k in TAIL_PARAM_ORDER)
 
-
-# ---------------------------------------------------------------------------------------------------------------------
-# the second half of a full encoder layer as one forward kernel (csrc/g2048_block.hip)
-# ---------------------------------------------------------------------------------------------------------------------
-BLOCK_PARAM_ORDER = ("wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2", "lnn_g", "lnn_b")
-
-
-class BlockPlan:
-    """What ``_BlockFFN`` needs besides its tensor inputs: the f32 masters by field name (``BLOCK_PARAM_ORDER``), the
-    fragment-packed bf16 weights the forward kernel streams, the row-major bf16 shadows the backward's GEMMs multiply with
-    (out_proj, linear1, linear2 and linear2 transposed), LayerNorm epsilons, dropout rate, and the CLS link of the residual
-    stream when the next layer only reads its CLS rows."""
-
-    def __init__(self, params, packed, dense, eps2, eps_next, p_drop, cls_link=None):
-        self.params, self.packed, self.dense = params, packed, dense
-        self.eps2, self.eps_next, self.p_drop, self.cls_link = float(eps2), float(eps_next), float(p_drop), cls_link
-
-
-class _BlockFFN(torch.autograd.Function):
-    """``x_mid = x + dropout(out_proj(a)); h2 = norm2(x_mid); u = dropout(relu(linear1(h2))); x_out = x_mid + dropout(linear2(u));
-    h_next = next_norm(x_out)`` -> (x_out f32, h_next bf16): ``g2048_block_fwd`` instead of out_proj GEMM + add/LayerNorm + fused
-    linear1 + linear2 GEMM + add/LayerNorm (five launches, 138 us per layer at 34 816 tokens).  a bf16 [B, S, 256] (attention
-    output), x f32 [B, S, 256].  The backward runs the kernels the three unfused nodes ran (``g2048_add_ln_bwd`` recomputes the
-    dropout masks of sites 1 and 3 from their seeds; the hidden activation's pattern is read off ``u``)."""
-
-    @staticmethod
-    def forward(ctx, a, x, plan, *params):
-        from ..g2048 import native as nv
-
-        ctx.set_materialize_grads(False)
-        shape = x.shape
-        M = x.numel() // 256
-        a2, x2 = a.reshape(M, 256).contiguous(), x.reshape(M, 256).contiguous()
-        P = plan.params
-        t = dict(plan.packed)
-        t.update({k: P[k].detach() for k in ("bo", "b1", "b2", "ln2_g", "ln2_b", "lnn_g", "lnn_b")})
-        W = nv.block_weights(t)
-        p = plan.p_drop
-        seeds = [_seed_pair(a2, p) for _ in range(3)]
-        out = nv.block_fwd(a2, x2, W, M, plan.eps2, plan.eps_next, p, [sd[0] for sd in seeds], seeds[0][1])
-        ctx.plan, ctx.seeds, ctx.shape, ctx.keep = plan, seeds, shape, t
-        if plan.cls_link is not None:
-            plan.cls_link.attached = x.dim() == 3
-        ctx.save_for_backward(a2, out["x_mid"], out["mean2"], out["rstd2"], out["h2"], out["u"], out["x_out"], out["mean_n"],
-                              out["rstd_n"])
-        return out["x_out"].view(shape), out["h_next"].view(shape)
-
-    @staticmethod
-    def backward(ctx, g_x, g_hn):
-        from ..g2048 import native as nv
-
-        a2, x_mid, mean2, rstd2, h2, u, x_out, mean_n, rstd_n = ctx.saved_tensors
-        plan, (sd1, _sd2, sd3) = ctx.plan, ctx.seeds
-        P, Dn, p = plan.params, plan.dense, plan.p_drop
-        T, dev, bf = x_mid.shape[0], x_mid.device, torch.bfloat16
-        sink = _sink_for(*[P[k] for k in BLOCK_PARAM_ORDER])
-        grads = {}
-
-        def partials(name, ws, stride, n):  # first-stage partial sums [rows, stride] (first n columns) -> the sink, or summed here
-            if sink is not None:
-                sink.add(P[name], ws, stride, n, ws.shape[0])
-            else:
-                grads[name] = ws[:, :n].sum(0).to(P[name].dtype)
-
-        def weight(name, dy, xin):
-            if sink is not None:
-                _sink_weight(sink, P[name], dy, xin)
-            else:
-                grads[name] = _dweight(dy, xin).to(P[name].dtype)
-
-        # ---- next LayerNorm + the residual add after linear2 (site 3)
-        period = 1
-        cl = plan.cls_link
-        if cl is not None and cl.g is not None:  # the stream's only gradient: the CLS rows, from _ClsRows
-            if g_x is not None:
-                raise RuntimeError("the residual stream entering the CLS-only layer has a second consumer")
-            g_x, period, cl.g = cl.g, ctx.shape[1], None
-        if g_hn is None:
-            g_hn = torch.zeros((T, 256), dtype=bf, device=dev)
-        dx = torch.empty((T, 256), dtype=torch.float32, device=dev)
-        da3 = torch.empty((T, 256), dtype=bf, device=dev)
-        ws = nv.add_ln_bwd(x_out.data_ptr(), 256, None if g_x is None else g_x.contiguous(), g_hn.reshape(T, 256).contiguous(), mean_n,
-                           rstd_n, P["lnn_g"].detach(), dx, da3, None, T, p, *sd3, g_x_period=period)
-        partials("lnn_g", ws, 768, 256)
-        partials("lnn_b", ws[:, 256:], 768, 256)
-        partials("b2", ws[:, 512:], 768, 256)
-        with torch.autocast("cuda", enabled=False):
-            # ---- linear2, ReLU + dropout (site 2: the pattern is u's), linear1
-            du = _hip_linear(da3, Dn["w2T"])
-            if du is None:
-                du = da3 @ Dn["w2"]
-            dz = torch.empty_like(u)
-            ws1 = nv.relu_dropout_bwd(du, u, dz, None, p)
-            partials("b1", ws1, ws1.shape[1], ws1.shape[1])
-            weight("w2", da3, u)
-            weight("w1", dz, h2)
-            dh2 = dz @ Dn["w1"]
-            # ---- LayerNorm2 + the residual add after out_proj (site 1)
-            dx2 = torch.empty((T, 256), dtype=torch.float32, device=dev)
-            da1 = torch.empty((T, 256), dtype=bf, device=dev)
-            ws2 = nv.add_ln_bwd(x_mid.data_ptr(), 256, dx, dh2, mean2, rstd2, P["ln2_g"].detach(), dx2, da1, None, T, p, *sd1)
-            partials("ln2_g", ws2, 768, 256)
-            partials("ln2_b", ws2[:, 256:], 768, 256)
-            partials("bo", ws2[:, 512:], 768, 256)
-            d_a = (da1 @ Dn["wo"]).view(ctx.shape) if ctx.needs_input_grad[0] else None
-            weight("wo", da1, a2)
-        if sink is None:
-            return (d_a, dx2.view(ctx.shape), None) + tuple(grads[k] for k in BLOCK_PARAM_ORDER)
-        return (d_a, dx2.view(ctx.shape), None) + (None,) * len(BLOCK_PARAM_ORDER)

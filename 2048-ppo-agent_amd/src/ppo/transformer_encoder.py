@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..env_definitions import BOARD_DIM
-from .hip_ops import (BLOCK_PARAM_ORDER, Bf16Shadow, BlockPlan, ClsLink, FFNLink, _BlockFFN, _AddLayerNorm, _ClsRows, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
+from .hip_ops import (Bf16Shadow, ClsLink, FFNLink, _AddLayerNorm, _ClsRows, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
                       _LinearAddCast, _LinearAddLayerNorm, _LinearReluDropout, _LinearSplitK, _add_norm, _fused_attention_ok, _fused_norm_ok,
                       _linear, _train_bf16, graph_seed_state)
 
@@ -88,10 +88,9 @@ class TransformerEncoder(nn.Module):
                        l.self_attn.out_proj.bias, l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias]
             last = len(layers) - 1
             # [in, out] copies: linear2 of every layer (masked input-gradient GEMM); fragment-packed copies (tensor and transpose) of
-            # out_proj, linear1 and linear2 of EVERY layer (g2048_block_fwd for the full layers, the fused CLS tail for the last)
+            # out_proj, linear1 and linear2 of the LAST layer (the fused CLS tail, g2048_cls_tail_fwd / _bwd)
             self._shadow = Bf16Shadow(ps, transposed=[8 * i + 6 for i in range(len(layers))],
-                                      packed=[8 * i + o for i in range(len(layers)) for o in (2, 4, 6)])
-            del last
+                                      packed=[8 * last + 2, 8 * last + 4, 8 * last + 6])
         v = self._shadow()
         return [v[8 * i:8 * i + 8] + [self._shadow.tviews[8 * i + 6]] for i in range(len(layers))]
 
@@ -140,18 +139,6 @@ class TransformerEncoder(nn.Module):
                                          b2=layer.linear2.bias),
                               {k: pv[8 * i_last + o] for k, o in (("wo", 2), ("w1", 4), ("w2", 6))},
                               {k: ptv[8 * i_last + o] for k, o in (("wo", 2), ("w1", 4), ("w2", 6))}, n2.eps, p), None
-        if (not cls_only and next_norm is not None and sh[0] is not None and a.dtype == torch.bfloat16 and _fused_norm_ok(x, None)
-                and D == 256 and layer.linear1.out_features == 1024 and x.dim() == 3):
-            # update path, full layer: everything after the attention as one forward kernel (g2048_block_fwd)
-            li = list(self.encoder.layers).index(layer)
-            pv = self._shadow.pviews
-            n2 = layer.norm2
-            params = dict(wo=attn.out_proj.weight, bo=attn.out_proj.bias, ln2_g=n2.weight, ln2_b=n2.bias, w1=layer.linear1.weight,
-                          b1=layer.linear1.bias, w2=layer.linear2.weight, b2=layer.linear2.bias, lnn_g=next_norm.weight,
-                          lnn_b=next_norm.bias)
-            plan = BlockPlan(params, {k: pv[8 * li + o] for k, o in (("wo", 2), ("w1", 4), ("w2", 6))},
-                             dict(wo=sh[2], w1=sh[4], w2=sh[6], w2T=sh[8]), n2.eps, next_norm.eps, p, cls_link_out)
-            return _BlockFFN.apply(a, x, plan, *[params[k] for k in BLOCK_PARAM_ORDER])
         if sh[0] is not None and a.dtype == torch.bfloat16 and _fused_norm_ok(x, None) \
                 and layer.linear1.out_features % 8 == 0 and layer.linear1.out_features <= 2048:
             # update path: out_proj + add + LayerNorm, linear1 + ReLU + dropout, linear2 + add + LayerNorm as three ops

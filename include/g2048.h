@@ -444,35 +444,6 @@ int g2048_cls_tail_bwd(const float *dlogits, const float *dvalues, const g2048_t
                        const g2048_tail_grads *G, void *d_o, float *dx_cls, int64_t M, float p_drop, uint64_t seed,
                        const uint64_t *seed_state, void *stream);
 
-/* ---- policy network (update): the second half of a full encoder layer as one kernel ---------------------------------- */
-
-/* x_mid = x + dropout(out_proj(a)); h2 = LayerNorm(norm2)(x_mid); u = dropout(relu(linear1(h2)));
- * x_out = x_mid + dropout(linear2(u)); h_next = LayerNorm(next)(x_out)        for M token rows, d_model 256, feed-forward 1024
- * (reference: nn.TransformerEncoderLayer(norm_first=True), src/ppo/transformer_encoder.py:138-148 - the residual add after
- * _sa_block, _ff_block with its residual add - plus norm1 of the following layer, whose input it produces).
- * wo / w1 / w2: fragment-packed bf16 weights ([256][256], [1024][256], [256][1024]); biases and LayerNorm parameters f32. */
-typedef struct {
-    const void *wo, *w1, *w2;
-    const float *bo, *b1, *b2;
-    const float *ln2_g, *ln2_b, *lnn_g, *lnn_b;
-} g2048_block_weights;
-/* everything below is written by the forward: row-major [M][256] (x_mid, x_out f32; h2, h_next bf16), u bf16 [M][1024],
- * LayerNorm statistics f32 [M], bits = g2048_block_bits_bytes(M) bytes (one bit per element of u: non-zero or not, in the
- * kernel's accumulator layout) */
-typedef struct {
-    float *x_mid, *mean2, *rstd2;
-    void *h2, *u, *bits;
-    float *x_out, *mean_n, *rstd_n;
-    void *h_next;
-} g2048_block_saved;
-int64_t g2048_block_bits_bytes(int64_t M);
-/* a: bf16 [M][256] (attention output), x: f32 [M][256] (residual stream).  Dropout sites 1 (after out_proj) and 3 (after linear2)
- * use the decision function of g2048_add_ln_fwd with seed1 / seed3, so that g2048_add_ln_bwd recomputes their masks; site 2 (the
- * hidden activation) travels as the non-zero pattern of u. */
-int g2048_block_fwd(const void *a, const float *x, const g2048_block_weights *W, const g2048_block_saved *S, int64_t M, float eps2,
-                    float eps_next, float p_drop, uint64_t seed1, uint64_t seed2, uint64_t seed3, const uint64_t *seed_state,
-                    void *stream);
-
 /* Weight gradients from transposed operands, all jobs in one launch: for job j,
  * dw[s][n][k] = sum over the s-th of `slices` equal pieces of the row axis of dyT[n][m] * xT[k][m]   (f32 [slices][N][K]),
  * db[s][n]    = the same sum of dyT[n][m]                                                        (f32 [slices][N], or NULL);
