@@ -133,7 +133,7 @@ def test_optimiser_keeps_bf16_shadows_current(dev, tmp_path, monkeypatch):
     mine = {id(p) for p in agent.parameters()}
     shadows = [s for s in Bf16Shadow._live if s.views is not None and all(id(p) in mine for p in s.params)]
     assert len(shadows) >= 2 and all(s.maintainer is tr._flat_step for s in shadows)  # encoder layers + heads
-XX
+    assert sum(len(s.packed) for s in shadows) == 7  # the last layer's out_proj / linear1 / linear2 + four head matrices
     def check():
         for s in shadows:
             assert s.key == s.current_key()
