@@ -271,6 +271,9 @@ def cpu_baseline(boards: int, total_seconds: float = 18.0):
             "sample": f"{sample[0]} x {boards} random-policy episodes ({sample[1]} env-steps, {sample[2]:.1f} s) on {all_threads} OpenMP "
                       f"threads; env + RNG + policy draw only (no policy network); C restatement of the Pgx 2048 env "
                       f"(oracle/g2048_oracle.c), bit-exact vs the reference's golden frames",
+            "unpinned_semantics": "no reference artifact pins three env rules the oracle (and the kernels) restate from Pgx: the merge-reward "
+                                  "magnitude, -1 on an illegal action, the spawn on a full board going to cell 0 (DESIGN.md 4); rewards "
+                                  "feed GAE and the loss",
             "cpu_model": model, "logical_cpus": os.cpu_count(), "physical_cores": phys, "matrix": matrix}
 
 
