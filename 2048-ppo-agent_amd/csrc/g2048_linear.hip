@@ -180,32 +180,65 @@ k_linear(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ w
     store_tile<HAS_BIAS, EPI_NONE>(acc, bias, y + (tok0 + r) * ldy + n0 + 8 * h, n0, h, valid, Epi{}, 0, nullptr, make_uint2(0u, 0u), nullptr);
 }
 
-// K <= 256: the weight slice (<= 64 KiB) is loaded ONCE and stays in LDS; the workgroup then walks over token tiles
-// blockIdx.x, blockIdx.x + gridDim.x, ... with the next half-row of B always in flight behind the current MFMAs.
-template <bool HAS_BIAS, int EPI>
-__global__ void __launch_bounds__(THREADS, 2)
-k_linear_stationary(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ wgt, int64_t ldw,
-                    const float *__restrict__ bias, __bf16 *__restrict__ y, int64_t ldy, int64_t T, int K, Epi E) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * NS;
-    const __bf16 *w_slice = wgt + (size_t)n0 * ldw;
-    const int n_chunks = K / KC;  // 1 or 2
-    const int64_t n_tiles = (T + TOK - 1) / TOK;
+// K <= 256, round 3: weights stationary in REGISTERS, tokens through LDS.
+// Round 2's kernel kept the weight slice in LDS and let every lane walk its own token row in global memory (the B operand: 16 bytes
+// per lane and k-step).  A wave-instruction of that kind is 64 separate 16-byte requests (lane = row); rocprofv3 showed the waves
+// stalled at instruction issue for 58 % of their cycles (SQ_WAIT_INST_ANY) at 2.0-2.4 TB/s, and neither the instruction order nor the
+// store pattern moved it.  Here the roles are swapped:
+//   * the four waves split the slice's 128 OUTPUT features (one 32-row weight tile each): a wave's whole weight tile over K <= 256 is
+//     16 fragments = 64 registers, loaded once per workgroup from nn.Linear's row-major layout;
+//   * a 128-token tile of X is copied into LDS by LDS-DMA (`global_load_lds`, whole 512-byte rows: perfectly coalesced, no
+//     registers), 16-byte chunks XOR-swizzled by row so that every B fragment is one conflict-free ds_read_b128; every wave multiplies
+//     its weight tile against all four token blocks;
+//   * the output tile goes back through the same LDS buffer (row-major, swizzled) and leaves as full 256-byte rows.
+// 64 KiB of LDS per workgroup = two workgroups per CU: one's DMA hides behind the other's MFMAs and stores.
+// Accumulator tile of wave w, token block b: acc[b][i] = Y^T[n0 + 32 w + rowof(i, h)][token 32 b + r].
+__device__ __forceinline__ int rowof(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-    auto row_of = [&](int64_t tile) -> const uint4 * {
-        int64_t tok = tile * TOK + 32 * w + r;
-        if (tok >= T) tok = T - 1;
-        return reinterpret_cast<const uint4 *>(x + tok * ldx) + h;
-    };
-    const uint4 *xrow = row_of(blockIdx.x);
-    uint4 bq[8];
-    for (int ks = 0; ks < 8; ++ks) bq[ks] = xrow[2 * ks];
-    for (int c = 0; c < n_chunks; ++c) dma_chunk(smem + c * CHUNK_BYTES, w_slice, ldw, c, w, lane);
-    int aoff[8];
-    for (int ks = 0; ks < 8; ++ks) aoff[ks] = r * 256 + (((2 * ks + h) ^ (r & 15)) * 16);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+// X tile [64 tokens][K] -> LDS rows of K * 2 bytes, chunk q of row r at q ^ (r & 15); K = 256: 32 wave-instructions of 1 KiB (2 rows)
+constexpr int TOKW = 64;  // tokens per tile of k_linear_ws
+__device__ __forceinline__ void dma_x_tile(char *dst, const __bf16 *x, int64_t ldx, int64_t tok0, int64_t T, int K, int w, int lane) {
+    const int cpr = K / 8;                 // 16-byte chunks per row: 32 (K = 256) or 16 (K = 128)
+    const int rows_per_inst = 64 / cpr;    // 2 or 4
+    const int n_inst = TOKW / rows_per_inst / 4;
+    for (int t = 0; t < n_inst; ++t) {
+        const int n = 4 * t + w;
+        const int row = n * rows_per_inst + lane / cpr, p = lane % cpr;
+        const int q = p ^ (row & 15);
+        int64_t tok = tok0 + row;
+        if (tok >= T) tok = T - 1;  // clamped: the rows past T are computed and not stored
+        const char *g = reinterpret_cast<const char *>(x + tok * ldx) + q * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(dst + n * 1024), 16, 0, 0);
+    }
+}
+
+// NT = weight tiles per wave: the workgroup's slice of N is 128 NT outputs wide.  Only NT = 1 is instantiated: NT = 2 (256-wide
+// slices, half the X re-reads through the CU's memory pipes) was measured in round 3 and lost -- 247..256 VGPRs with up to 216 B of
+// scratch, 35.2 vs 33.9 us at N = 1024 in isolation and 204 vs 137 us/minibatch for the mask-backward variant.
+template <bool HAS_BIAS, int EPI, int NT = 1>
+__global__ void __launch_bounds__(THREADS, 2)
+k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ wgt, int64_t ldw, const float *__restrict__ bias,
+            __bf16 *__restrict__ y, int64_t ldy, int64_t T, int K, Epi E) {
+    constexpr int NSW = NS * NT, CPR_Y = NSW / 8;  // slice width; 16-byte chunks per staging row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.y * NSW;
+    const int KS = K / 16, row_bytes = K * 2;
+
+    // ---- this wave's weight tiles: rows n0 + 32 (NT w + t) .. + 31, all of K (fragment ks = columns 16 ks + 8 h .. + 7 of row .. + r)
+    bf16x8 wf[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int nw = n0 + 32 * (NT * w + t);
+        const __bf16 *wrow = wgt + (size_t)(nw + r) * ldw + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) wf[t][ks] = ks < KS ? *reinterpret_cast<const bf16x8 *>(wrow + 16 * ks) : bf16x8{};
+    }
+    // the slice's bias in LDS (behind the staging tile): it enters through the accumulators' initial value, 4 broadcast reads per tile
+    float *const bias_l = reinterpret_cast<float *>(smem + TOKW * row_bytes + TOKW * 2 * NSW);
+    for (int i = tid; i < NSW; i += THREADS) bias_l[i] = HAS_BIAS ? bias[n0 + i] : 0.f;
     if (EPI == EPI_RELU_DROPOUT) {
         if (E.seed_state) {
             const uint64_t sd = *E.seed_state;  // same mixing as the other dropout kernels (g2048_layernorm.hip)
@@ -215,57 +248,125 @@ k_linear_stationary(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__r
         E.hi_term = E.s0 ^ (E.s1 * 0x85EBCA77u);
     }
     const int slices = gridDim.y;
-    float colacc[EPI == EPI_MASK_COLSUM ? 64 : 1];
-    for (int q = 0; q < (EPI == EPI_MASK_COLSUM ? 64 : 1); ++q) colacc[q] = 0.f;
-
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t next = tile + gridDim.x;
-        const uint4 *xnext = row_of(next < n_tiles ? next : tile);
-        uint2 *bits_slot = (EPI != EPI_NONE && E.bits) ? E.bits + ((tile * slices + blockIdx.y) * THREADS + tid) : nullptr;
-        uint2 bits_in = make_uint2(0u, 0u);
-        if (EPI == EPI_MASK_COLSUM) bits_in = *bits_slot;  // 8 bytes per lane, in flight behind the MFMAs
-        f32x16 acc[4];
-        for (int j = 0; j < 4; ++j)
-            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-        for (int c = 0; c < n_chunks; ++c) {
-            bf16x8 b[8];
-            for (int ks = 0; ks < 8; ++ks) b[ks] = *reinterpret_cast<const bf16x8 *>(&bq[ks]);
-            // prefetch: the other half of this row, or the first half of the next tile's row
-            const uint4 *src = (c + 1 < n_chunks) ? xrow + 16 * (c + 1) : xnext;
-            for (int ks = 0; ks < 8; ++ks) bq[ks] = src[2 * ks];
-            const char *img = smem + c * CHUNK_BYTES;
-            for (int ks = 0; ks < 8; ++ks)
-                for (int j = 0; j < 4; ++j) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(img + aoff[ks] + j * 32 * 256);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[ks], acc[j], 0, 0, 0);
+    float colacc[EPI == EPI_MASK_COLSUM ? NT * 16 : 1];  // per-lane sums over this workgroup's tokens of the lane's output rows
+    for (int q = 0; q < (EPI == EPI_MASK_COLSUM ? NT * 16 : 1); ++q) colacc[q] = 0.f;
+    // LDS: one X tile (the second workgroup of the CU computes while this one waits) + the output staging tile
+    char *const stage = smem + TOKW * row_bytes;
+    const int64_t n_tiles64 = (T + TOKW - 1) / TOKW;
+    // NT 32-bit words per thread and 64-token tile: bit 16 b + i of word t <-> accumulator (t, b, i) of this lane
+    auto bits_ptr = [&](int64_t tile) -> uint32_t * {
+        return (EPI != EPI_NONE && E.bits) ? reinterpret_cast<uint32_t *>(E.bits) + ((tile * slices + blockIdx.y) * THREADS + tid) * NT
+                                           : nullptr;
+    };
+    for (int64_t tile = blockIdx.x; tile < n_tiles64; tile += gridDim.x) {
+        const int64_t tok0 = tile * TOKW;
+        dma_x_tile(smem, x, ldx, tok0, T, K, w, lane);
+        uint32_t bits_in[NT];
+        for (int t = 0; t < NT; ++t) bits_in[t] = EPI == EPI_MASK_COLSUM ? bits_ptr(tile)[t] : 0u;  // in flight with the tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the tile has landed for every wave (and every wave is done storing the previous one)
+        f32x16 acc[NT][2];
+        for (int t = 0; t < NT; ++t)
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bias_l + 32 * (NT * w + t) + 8 * g + 4 * h);
+                for (int b = 0; b < 2; ++b) {
+                    acc[t][b][4 * g + 0] = bv.x; acc[t][b][4 * g + 1] = bv.y; acc[t][b][4 * g + 2] = bv.z; acc[t][b][4 * g + 3] = bv.w;
                 }
+            }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks < KS) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(smem + (32 * b + r) * row_bytes + (((2 * ks + h) ^ (r & 15)) * 16));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], bf, acc[t][b], 0, 0, 0);
+                }
+            }
         }
-        const int64_t tok = tile * TOK + 32 * w + r;
-        store_tile<HAS_BIAS, EPI>(acc, bias, y + tok * ldy + n0 + 8 * h, n0, h, tok < T, E, tok < T ? tok : T - 1, bits_slot, bits_in,
-                                  colacc);
-        xrow = xnext;
+        // ---- epilogue: lane = token 32 b + r, registers 4g..4g+3 of tile t = output features n0 + 32 (NT w + t) + 8g + 4h .. +3
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int nw = n0 + 32 * (NT * w + t);
+            uint32_t obits = 0u;  // bit 16 b + i: output (t, b, i) of this lane is non-zero after rounding
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int64_t tok = tok0 + 32 * b + r;
+                const bool valid = tok < T;
+                if (EPI == EPI_RELU_DROPOUT) {
+                    // one 32-bit hash per pair of neighbouring columns, 16 bits each (index = element index / 2, the seed's high
+                    // word through E.hi_term: the convention of the round-2 kernel)
+                    const uint32_t pair0 = (uint32_t)(((uint64_t)(valid ? tok : T - 1) * (uint64_t)E.row_elems + (uint64_t)(nw + 4 * h)) >> 1);
+                    for (int i = 0; i < 16; i += 2) {
+                        float a = fmaxf(acc[t][b][i], 0.f), c = fmaxf(acc[t][b][i + 1], 0.f);
+                        if (E.thr16) {
+                            uint32_t xh = (pair0 + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2))) * 0x9E3779B1u + E.hi_term;
+                            xh ^= xh >> 16; xh *= 0x7FEB352Du; xh ^= xh >> 15; xh *= 0x846CA68Bu; xh ^= xh >> 16;
+                            a = (xh & 0xFFFFu) >= E.thr16 ? a * E.inv_keep : 0.f;
+                            c = (xh >> 16) >= E.thr16 ? c * E.inv_keep : 0.f;
+                        }
+                        acc[t][b][i] = a; acc[t][b][i + 1] = c;
+                    }
+                }
+                if (EPI == EPI_MASK_COLSUM) {
+                    const uint32_t wbits = bits_in[t] >> (16 * b);
+                    for (int i = 0; i < 16; ++i) acc[t][b][i] = ((wbits >> i) & 1u) ? acc[t][b][i] * E.inv_keep : 0.f;
+                }
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t lo = pack2(acc[t][b][4 * g + 0], acc[t][b][4 * g + 1]), hi = pack2(acc[t][b][4 * g + 2], acc[t][b][4 * g + 3]);
+                    if (EPI == EPI_RELU_DROPOUT) {
+                        const uint32_t nz = ((lo & 0x7FFFu) ? 1u : 0u) | ((lo & 0x7FFF0000u) ? 2u : 0u) | ((hi & 0x7FFFu) ? 4u : 0u) |
+                                            ((hi & 0x7FFF0000u) ? 8u : 0u);
+                        obits |= nz << (16 * b + 4 * g);
+                    }
+                    if (EPI == EPI_MASK_COLSUM && valid) {  // what at::sum over the bf16 tensor would add
+                        colacc[16 * t + 4 * g + 0] += __uint_as_float(lo << 16);
+                        colacc[16 * t + 4 * g + 1] += __uint_as_float(lo & 0xFFFF0000u);
+                        colacc[16 * t + 4 * g + 2] += __uint_as_float(hi << 16);
+                        colacc[16 * t + 4 * g + 3] += __uint_as_float(hi & 0xFFFF0000u);
+                    }
+                    // staging tile: rows of 2 NSW bytes, 16-byte chunk c of row q at c ^ (q & (CPR_Y - 1)); this piece = half a chunk
+                    const int trow = 32 * b + r, c = 4 * (NT * w + t) + g;
+                    *reinterpret_cast<uint2 *>(stage + trow * (2 * NSW) + ((c ^ (trow & (CPR_Y - 1))) * 16) + 8 * h) = make_uint2(lo, hi);
+                }
+            }
+            if (EPI == EPI_RELU_DROPOUT && E.bits) bits_ptr(tile)[t] = obits;
+        }
+        __syncthreads();  // the output tile is complete (and every wave is done reading the X tile)
+        for (int e = tid; e < TOKW * CPR_Y; e += THREADS) {
+            const int trow = e / CPR_Y, p = e % CPR_Y, c = p ^ (trow & (CPR_Y - 1));
+            if (tok0 + trow < T)
+                *reinterpret_cast<uint4 *>(y + (tok0 + trow) * ldy + n0 + 8 * c) =
+                    *reinterpret_cast<const uint4 *>(stage + trow * (2 * NSW) + p * 16);
+        }
+        // (the next iteration's barrier separates these reads of the staging tile from the next epilogue's writes)
     }
     if (EPI == EPI_MASK_COLSUM) {
-        // column sums of this workgroup's tiles: lane (r, h) of wave w holds, for its tokens, columns
-        // 32j + 16m + 8h + e at colacc[8(2j + m) + e].  Through LDS (the weight image is no longer needed):
-        // red[w][q][lane], then thread c < 128 adds the 4 x 32 values of column c in a fixed order.
-        __syncthreads();
-        float *red = reinterpret_cast<float *>(smem);
-        for (int q = 0; q < 64; ++q) red[(w * 64 + q) * 64 + lane] = colacc[q];
-        __syncthreads();
-        if (tid < NS) {
-            const int c = tid, q = 8 * (c >> 4) + (c & 7), hh = (c >> 3) & 1;
-            float sum = 0.f;
-            for (int ww = 0; ww < THREADS / 64; ++ww)
-                for (int rr = 0; rr < 32; ++rr) sum += red[(ww * 64 + q) * 64 + 32 * hh + rr];
-            E.partial[(int64_t)blockIdx.x * E.N + n0 + c] = sum;
-        }
+        // column sums: register q of tile t of lane (r, h) = output feature n0 + 32 (NT w + t) + rowof(q, h) over this lane's tokens
+        for (int t = 0; t < NT; ++t)
+            for (int q = 0; q < 16; ++q) {
+                float v = colacc[16 * t + q];
+                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+                if (r == 0) E.partial[(int64_t)blockIdx.x * E.N + n0 + 32 * (NT * w + t) + rowof(q, h)] = v;
+            }
     }
 }
 
 }  // namespace
 
 namespace {
+
+// workgroup rows of k_linear_ws: 512 resident workgroups shared between the N-slices.  XCD locality: workgroup (x, y) has linear id
+// x + y * groups and the dispatcher deals linear ids round-robin over the 8 XCDs, so the N-slices y of one token tile x share an XCD
+// (and its L2 copy of the X rows) only if groups % 8 == 0.  Measured in round 2 with N = 768 (groups 85): 98.8 MB of HBM reads per
+// launch for a 17.8 MB X (rocprofv3 FETCH_SIZE).
+inline int64_t ws_groups(int64_t T, int N, int NT = 1) {
+    const int64_t n_tiles = (T + TOKW - 1) / TOKW;
+    int64_t groups = 512 / (N / (NS * NT));
+    if (groups < 1) groups = 1;
+    if (groups >= 8) groups -= groups % 8;
+    return groups > n_tiles ? n_tiles : groups;
+}
 
 inline bool operands_ok(const void *x, int64_t ldx, const void *weight, int64_t ldw, const void *y, int64_t ldy, int64_t T, int K,
                         int N, const void *bias) {
@@ -274,29 +375,29 @@ inline bool operands_ok(const void *x, int64_t ldx, const void *weight, int64_t 
 }
 
 // K <= 256: weights-stationary kernel, two workgroups per CU on 256 CUs shared between the N-slices
+template <bool HAS_BIAS, int EPI, int NT = 1>
+int launch_ws(const __bf16 *x, int64_t ldx, const __bf16 *w, int64_t ldw, const float *bias, __bf16 *y, int64_t ldy, int64_t T, int K,
+              int N, const Epi &E, int *groups_out, hipStream_t stream) {
+    const void *fn = reinterpret_cast<const void *>(k_linear_ws<HAS_BIAS, EPI, NT>);
+    // one 64-token tile of X (K <= 256: 32 KiB) + the output staging tile (16 KiB per 128 outputs): 48 / 64 KiB, two workgroups per CU
+    const int lds_max = TOKW * 256 * 2 + TOKW * NS * NT * 2 + NS * NT * 4;
+    // the dynamic-LDS limit is a per-device attribute of the one kernel this call launches: set per call, no latch
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) return -(1000 + (int)hipGetLastError());
+    const int64_t n_tiles = (T + TOKW - 1) / TOKW;
+    const int slices = N / (NS * NT);
+    int64_t groups = ws_groups(T, N, NT);
+    if (groups_out) *groups_out = (int)groups;
+    (void)n_tiles;
+    const int lds = TOKW * K * 2 + TOKW * NS * NT * 2 + NS * NT * 4;
+    hipLaunchKernelGGL((k_linear_ws<HAS_BIAS, EPI, NT>), dim3((unsigned)groups, (unsigned)slices), dim3(THREADS), lds, stream, x, ldx, w,
+                       ldw, bias, y, ldy, T, K, E);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(1000 + (int)e);
+}
 template <bool HAS_BIAS, int EPI>
 int launch_stationary(const __bf16 *x, int64_t ldx, const __bf16 *w, int64_t ldw, const float *bias, __bf16 *y, int64_t ldy, int64_t T,
                       int K, int N, const Epi &E, int *groups_out, hipStream_t stream) {
-    const void *fn = reinterpret_cast<const void *>(k_linear_stationary<HAS_BIAS, EPI>);
-    // the dynamic-LDS limit is a per-device attribute of the one kernel this call launches: set per call, no latch
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * CHUNK_BYTES) != hipSuccess)
-        return -(1000 + (int)hipGetLastError());
-    const int64_t n_tiles = (T + TOK - 1) / TOK;
-    const int slices = N / NS;
-    int64_t groups = 512 / slices;
-    if (groups < 1) groups = 1;
-    // XCD locality: workgroup (x, y) has linear id x + y * groups and the dispatcher deals linear ids round-robin over the
-    // 8 XCDs, so the N-slices y of one token tile x share an XCD (and its L2 copy of the X rows) only if groups % 8 == 0.
-    // Measured with N = 768 (groups 85): 98.8 MB of HBM reads per launch for a 17.8 MB X (rocprofv3 FETCH_SIZE).
-    if (groups >= 8) groups -= groups % 8;
-    if (groups > n_tiles) groups = n_tiles;
-    if (groups_out) *groups_out = (int)groups;
-    // the column-sum epilogue reuses the whole 64 KiB as its reduction buffer
-    const int lds = EPI == EPI_MASK_COLSUM ? NBUF * CHUNK_BYTES : (K / KC) * CHUNK_BYTES;
-    hipLaunchKernelGGL((k_linear_stationary<HAS_BIAS, EPI>), dim3((unsigned)groups, (unsigned)slices), dim3(THREADS), lds, stream, x,
-                       ldx, w, ldw, bias, y, ldy, T, K, E);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : -(1000 + (int)e);
+    return launch_ws<HAS_BIAS, EPI>(x, ldx, w, ldw, bias, y, ldy, T, K, N, E, groups_out, stream);
 }
 
 }  // namespace
@@ -349,11 +450,7 @@ extern "C" int64_t g2048_linear_mask_bwd_workspace_floats(int64_t T, int N) {
 
 extern "C" int64_t g2048_linear_mask_bwd_partial_rows(int64_t T, int N) {
     if (T <= 0 || N < NS || N % NS) return 0;
-    int64_t groups = 512 / (N / NS);
-    const int64_t n_tiles = (T + TOK - 1) / TOK;
-    if (groups < 1) groups = 1;
-    if (groups >= 8) groups -= groups % 8;  // as launch_stationary
-    return groups > n_tiles ? n_tiles : groups;
+    return ws_groups(T, N);
 }
 
 extern "C" int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const void *weight_t, int64_t ldw, const void *mask_bits,

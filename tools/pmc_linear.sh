@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 passes for k_linear_stationary at [34816, 256] x [256 -> 1024], cold operands -> gpurun_out/lin/linear_pmc.json
+# rocprofv3 passes for k_linear_ws at [34816, 256] x [256 -> 1024], cold operands -> gpurun_out/lin/linear_pmc.json
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf /tmp/pl && mkdir -p gpurun_out/lin
@@ -16,12 +16,12 @@ d = {}
 for p in ("p1", "p2", "p3", "p4"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f"gpurun_out/lin/{p}.csv")):
-        if "k_linear_stationary" in r["Kernel_Name"]:
+        if "k_linear_ws" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         d[k] = sum(v) / len(v)
 for r in csv.DictReader(open("gpurun_out/lin/kernel_stats.csv")):
-    if "k_linear_stationary" in r["Name"]:
+    if "k_linear_ws" in r["Name"]:
         d["avg_ns"] = float(r["AverageNs"]); d["calls"] = int(r["Calls"])
 d["mfma_util"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8 * 1024)
 d["wait_any_frac"] = d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]
