@@ -195,49 +195,141 @@ k_linear(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ w
 // Accumulator tile of wave w, token block b: acc[b][i] = Y^T[n0 + 32 w + rowof(i, h)][token 32 b + r].
 __device__ __forceinline__ int rowof(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-// X tile [64 tokens][K] -> LDS rows of K * 2 bytes, chunk q of row r at q ^ (r & 15); K = 256: 32 wave-instructions of 1 KiB (2 rows)
-constexpr int TOKW = 64;  // tokens per tile of k_linear_ws
-__device__ __forceinline__ void dma_x_tile(char *dst, const __bf16 *x, int64_t ldx, int64_t tok0, int64_t T, int K, int w, int lane) {
-    const int cpr = K / 8;                 // 16-byte chunks per row: 32 (K = 256) or 16 (K = 128)
-    const int rows_per_inst = 64 / cpr;    // 2 or 4
-    const int n_inst = TOKW / rows_per_inst / 4;
-    for (int t = 0; t < n_inst; ++t) {
-        const int n = 4 * t + w;
-        const int row = n * rows_per_inst + lane / cpr, p = lane % cpr;
-        const int q = p ^ (row & 15);
-        int64_t tok = tok0 + row;
-        if (tok >= T) tok = T - 1;  // clamped: the rows past T are computed and not stored
-        const char *g = reinterpret_cast<const char *>(x + tok * ldx) + q * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)(dst + n * 1024), 16, 0, 0);
-    }
+// One LDS-DMA wave-instruction (BYTES per lane, lane l lands at lds + BYTES l), written as inline assembly ON PURPOSE: for the builtin
+// the compiler's wait-count pass makes every later LDS read of the wave wait for the DMA (it cannot tell the buffers of one dynamic
+// LDS array apart), i.e. `s_waitcnt vmcnt(0)` right after the fetch that is meant to stay in flight for a whole tile.  The waits for
+// these fetches are therefore all explicit (`s_waitcnt vmcnt(0)` + barrier in k_linear_ws).  Unknown to the compiler, they can only
+// make ITS counted waits longer, never shorter (vmcnt retires in order and they are younger than what it waits for or it waits for 0).
+// (m0 is "reserved" for the compiler; it writes it only right in front of its own LDS-DMA builtins, which this kernel does not use)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+template <int BYTES>
+__device__ __forceinline__ void dma_async(const void *g, void *lds) {
+    const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds);
+    if (BYTES == 16) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l) : "memory", "m0");
 }
 
-// NT = weight tiles per wave: the workgroup's slice of N is 128 NT outputs wide.  Only NT = 1 is instantiated: NT = 2 (256-wide
-// slices, half the X re-reads through the CU's memory pipes) was measured in round 3 and lost -- 247..256 VGPRs with up to 216 B of
-// scratch, 35.2 vs 33.9 us at N = 1024 in isolation and 204 vs 137 us/minibatch for the mask-backward variant.
-template <bool HAS_BIAS, int EPI, int NT = 1>
-__global__ void __launch_bounds__(THREADS, 2)
+// the same with a scalar base and a 32-bit per-lane offset: no vector arithmetic per instruction
+__device__ __forceinline__ void dma_async16(const void *sbase, uint32_t voff, void *lds) {
+    const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(l) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+// X tile [64 tokens][K] -> LDS rows of K * 2 bytes, chunk q of row r at q ^ (r & 15); K = 256: 32 wave-instructions of 1 KiB (2 rows
+// each), dealt to the FETCHERS fetching waves (see k_linear_ws): wave f issues instructions f, f + FETCHERS, ...
+constexpr int TOKW = 64;  // tokens per tile of k_linear_ws
+constexpr int FETCHERS = 2;
+// one X buffer of k_linear_ws: the 64-token tile, or the output staging tile it turns into (64 rows of the slice), whichever is larger
+__host__ __device__ constexpr int ws_xbytes(int K, int waves) { return TOKW * 2 * (K > 32 * waves ? K : 32 * waves); }
+template <int K>
+struct XTileDma {
+    static constexpr int CPR = K / 8, RPI = 64 / CPR, N_INST = TOKW / RPI;  // 16-byte chunks per row, rows per instruction
+    static constexpr int NVAR = 16 / RPI / FETCHERS;                         // distinct swizzles among ONE fetcher's instructions
+    uint32_t voff[NVAR];  // per-lane byte offset of this fetcher's instruction j (j % NVAR decides the swizzle): lane's row * ldx * 2 + 16 q
+    int sub, p;
+    __device__ __forceinline__ void init(int64_t ldx, int lane, int f) {
+        sub = lane / CPR, p = lane % CPR;
+        for (int v = 0; v < NVAR; ++v)
+            voff[v] = (uint32_t)(sub * ldx * 2) + 16u * (uint32_t)(p ^ ((RPI * (FETCHERS * v + f) + sub) & 15));
+    }
+    // whole tile inside [0, T): scalar row base per instruction, nothing on the vector ALU
+    __device__ __forceinline__ void full(char *dst, const __bf16 *x, int64_t ldx, int64_t tok0, int f) const {
+        const char *base = reinterpret_cast<const char *>(x + tok0 * ldx);
+#pragma unroll
+        for (int j = 0; j < N_INST / FETCHERS; ++j) {
+            const int n = FETCHERS * j + f;
+            dma_async16(base + (int64_t)n * RPI * ldx * 2, voff[j % NVAR], dst + n * 1024);
+        }
+    }
+    // last, partial tile: rows past T read row T - 1 (computed and not stored)
+    __device__ __forceinline__ void clamped(char *dst, const __bf16 *x, int64_t ldx, int64_t tok0, int64_t T, int f) const {
+        for (int j = 0; j < N_INST / FETCHERS; ++j) {
+            const int n = FETCHERS * j + f;
+            const int row = n * RPI + sub;
+            int64_t tok = tok0 + row;
+            if (tok >= T) tok = T - 1;
+            dma_async<16>(reinterpret_cast<const char *>(x + tok * ldx) + (p ^ (row & 15)) * 16, dst + n * 1024);
+        }
+    }
+};
+
+// Diagnostic build only (-DG2048_WS_STAMPS, tools/stamps_linear.py; never compiled into the product library): cycle stamps at the phase
+// boundaries of k_linear_ws, summed per phase by one fetching and one storing wave of every 16th workgroup row of slice 0.
+#ifdef G2048_WS_STAMPS
+constexpr int WS_PHASES = 8;
+__device__ unsigned long long g_ws_stamps[2][WS_PHASES];
+struct WsStamps {
+    unsigned long long last, acc[WS_PHASES];
+    __device__ __forceinline__ static unsigned long long now() {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    }
+    __device__ __forceinline__ void start() {
+        for (int i = 0; i < WS_PHASES; ++i) acc[i] = 0;
+        last = now();
+    }
+    __device__ __forceinline__ void mark(int k) {
+        const unsigned long long t = now();
+        acc[k] += t - last;
+        last = t;
+    }
+    __device__ __forceinline__ void flush(int lane, int w) {
+        if (lane == 0 && (w == 0 || w == FETCHERS) && blockIdx.y == 0 && blockIdx.x % 16 == 0)
+            for (int i = 0; i < WS_PHASES; ++i) atomicAdd(&g_ws_stamps[w == 0 ? 0 : 1][i], acc[i]);
+    }
+};
+#define WS_STAMP(k) stamps.mark(k)
+#else
+#define WS_STAMP(k)
+#endif
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. would make the storing waves
+// wait for their global stores at every barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Roles inside the workgroup (round 3, second form).  A wave's vmcnt counts loads AND stores and is waited for in order, so a wave
+// that both fetches tile i + 1 and stores tile i cannot wait for the one without the other (measured: double buffering with every wave
+// doing both changed nothing).  Here waves 0..1 issue ALL LDS-DMA fetches (X tile, mask words) and never store the output tile; waves
+// 2..3 copy the staged output tile to global memory and never wait on vmcnt at all.  X is double buffered: the fetch of tile i + 1 is
+// issued right after the barrier that publishes tile i and has the whole tile (MFMAs, epilogue, copy-out) to land.  The output is
+// staged in the X buffer it was computed from (one more barrier), so a workgroup needs 2 x 32 KiB + 2.5 KiB: two workgroups per CU.
+// WAVES = 4: a 128-wide slice of N per workgroup, two workgroups per CU; WAVES = 8: a 256-wide slice, one workgroup per CU - the X tile
+// is fetched once per 256 outputs.  What bounds the kernel is the CU's vector-memory path (one texture addresser per CU: ~45-60 cycles
+// per 1 KiB wave-instruction, LDS-DMA fetches and stores alike; `TA_TA_BUSY` 40 % while the L2 -> memory write path stalls 2 % of its
+// cycles, profiles/round3_linear_ws_mem_pmc.json): per 128 outputs and tile 32 fetch + 16 store instructions with WAVES = 4, 16 + 16
+// with WAVES = 8.
+template <bool HAS_BIAS, int EPI, int KS, int WAVES>  // KS = K / 16: 16 (K = 256) or 8 (K = 128)
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1)
 k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ wgt, int64_t ldw, const float *__restrict__ bias,
-            __bf16 *__restrict__ y, int64_t ldy, int64_t T, int K, Epi E) {
-    constexpr int NSW = NS * NT, CPR_Y = NSW / 8;  // slice width; 16-byte chunks per staging row
+            __bf16 *__restrict__ y, int64_t ldy, int64_t T, Epi E) {
+    constexpr int THREADS = 64 * WAVES, NSW = 32 * WAVES;  // slice width
+    constexpr int CPR_Y = NSW / 8;                          // 16-byte chunks per staging row
+    constexpr int K = 16 * KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.y * NSW;
-    const int KS = K / 16, row_bytes = K * 2;
+    constexpr int row_bytes = K * 2, xbytes = ws_xbytes(K, WAVES);
 
-    // ---- this wave's weight tiles: rows n0 + 32 (NT w + t) .. + 31, all of K (fragment ks = columns 16 ks + 8 h .. + 7 of row .. + r)
-    bf16x8 wf[NT][16];
+    // ---- this wave's weight tile: rows n0 + 32 w .. + 31, all of K (fragment ks = columns 16 ks + 8 h .. + 7 of row .. + r)
+    bf16x8 wf[KS];
+    {
+        const __bf16 *wrow = wgt + (size_t)(n0 + 32 * w + r) * ldw + 8 * h;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int nw = n0 + 32 * (NT * w + t);
-        const __bf16 *wrow = wgt + (size_t)(nw + r) * ldw + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) wf[t][ks] = ks < KS ? *reinterpret_cast<const bf16x8 *>(wrow + 16 * ks) : bf16x8{};
+        for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const bf16x8 *>(wrow + 16 * ks);
     }
-    // the slice's bias in LDS (behind the staging tile): it enters through the accumulators' initial value, 4 broadcast reads per tile
-    float *const bias_l = reinterpret_cast<float *>(smem + TOKW * row_bytes + TOKW * 2 * NSW);
+    // Two X buffers: the fetch of tile i + 1 is issued right after the barrier that publishes tile i.  (Issuing it later, while the
+    // storing waves copy tile i out - with a third buffer to keep the lead - measured SLOWER, 30.3 vs 28.5 us at N = 1024: fetches and
+    // stores go through the same texture addresser, and it is what bounds the kernel; overlapping them only makes both slower.)
+    constexpr int NB = 2;
+    // LDS: the X buffers, the slice's bias (it enters through the accumulators' initial value, 4 broadcast reads per tile), mask words
+    float *const bias_l = reinterpret_cast<float *>(smem + NB * xbytes);
+    uint32_t *const bits_l = reinterpret_cast<uint32_t *>(smem + NB * xbytes + NSW * 4);  // [NB][THREADS]
     for (int i = tid; i < NSW; i += THREADS) bias_l[i] = HAS_BIAS ? bias[n0 + i] : 0.f;
     if (EPI == EPI_RELU_DROPOUT) {
         if (E.seed_state) {
@@ -248,107 +340,151 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
         E.hi_term = E.s0 ^ (E.s1 * 0x85EBCA77u);
     }
     const int slices = gridDim.y;
-    float colacc[EPI == EPI_MASK_COLSUM ? NT * 16 : 1];  // per-lane sums over this workgroup's tokens of the lane's output rows
-    for (int q = 0; q < (EPI == EPI_MASK_COLSUM ? NT * 16 : 1); ++q) colacc[q] = 0.f;
-    // LDS: one X tile (the second workgroup of the CU computes while this one waits) + the output staging tile
-    char *const stage = smem + TOKW * row_bytes;
+    float colacc[EPI == EPI_MASK_COLSUM ? 16 : 1];  // per-lane sums over this workgroup's tokens of the lane's output rows
+    for (int q = 0; q < (EPI == EPI_MASK_COLSUM ? 16 : 1); ++q) colacc[q] = 0.f;
     const int64_t n_tiles64 = (T + TOKW - 1) / TOKW;
-    // NT 32-bit words per thread and 64-token tile: bit 16 b + i of word t <-> accumulator (t, b, i) of this lane
+    // one 32-bit word per thread and 64-token tile: bit 16 b + i <-> accumulator (b, i) of this lane
     auto bits_ptr = [&](int64_t tile) -> uint32_t * {
-        return (EPI != EPI_NONE && E.bits) ? reinterpret_cast<uint32_t *>(E.bits) + ((tile * slices + blockIdx.y) * THREADS + tid) * NT
-                                           : nullptr;
+        return reinterpret_cast<uint32_t *>(E.bits) + (tile * slices + blockIdx.y) * THREADS;
     };
-    for (int64_t tile = blockIdx.x; tile < n_tiles64; tile += gridDim.x) {
+    XTileDma<K> dma;
+    dma.init(ldx, lane, w);
+    auto fetch = [&](int64_t tile, int buf) {  // fetching waves only (w < FETCHERS)
+        if ((tile + 1) * TOKW <= T) dma.full(smem + buf * xbytes, x, ldx, tile * TOKW, w);
+        else dma.clamped(smem + buf * xbytes, x, ldx, tile * TOKW, T, w);
+        if (EPI == EPI_MASK_COLSUM) {
+            const uint32_t *g = bits_ptr(tile) + lane;
+#pragma unroll
+            for (int j = w; j < THREADS / 64; j += FETCHERS) dma_async<4>(g + 64 * j, bits_l + buf * THREADS + 64 * j);
+        }
+    };
+    const bool fetcher = w < FETCHERS;
+    if (fetcher && (int64_t)blockIdx.x < n_tiles64) fetch(blockIdx.x, 0);
+#ifdef G2048_WS_STAMPS
+    WsStamps stamps;
+    stamps.start();
+#endif
+    int buf = 0;
+    for (int64_t tile = blockIdx.x; tile < n_tiles64; tile += gridDim.x, buf ^= 1) {
         const int64_t tok0 = tile * TOKW;
-        dma_x_tile(smem, x, ldx, tok0, T, K, w, lane);
-        uint32_t bits_in[NT];
-        for (int t = 0; t < NT; ++t) bits_in[t] = EPI == EPI_MASK_COLSUM ? bits_ptr(tile)[t] : 0u;  // in flight with the tile
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // the tile has landed for every wave (and every wave is done storing the previous one)
-        f32x16 acc[NT][2];
-        for (int t = 0; t < NT; ++t)
-            for (int g = 0; g < 4; ++g) {
-                const float4 bv = *reinterpret_cast<const float4 *>(bias_l + 32 * (NT * w + t) + 8 * g + 4 * h);
-                for (int b = 0; b < 2; ++b) {
-                    acc[t][b][4 * g + 0] = bv.x; acc[t][b][4 * g + 1] = bv.y; acc[t][b][4 * g + 2] = bv.z; acc[t][b][4 * g + 3] = bv.w;
-                }
-            }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            if (ks < KS) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(smem + (32 * b + r) * row_bytes + (((2 * ks + h) ^ (r & 15)) * 16));
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], bf, acc[t][b], 0, 0, 0);
-                }
+        char *const xb = smem + buf * xbytes;
+        if (fetcher) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's fetch (issued a whole tile ago) has landed
+        WS_STAMP(0);
+        lds_barrier();  // ... for every wave; and every wave is done with the other buffer (copy-out of the previous tile)
+        WS_STAMP(1);
+        if (fetcher && tile + gridDim.x < n_tiles64) fetch(tile + gridDim.x, buf ^ 1);
+        WS_STAMP(2);
+        const uint32_t bits_in = EPI == EPI_MASK_COLSUM ? bits_l[buf * THREADS + tid] : 0u;
+        f32x16 acc[2];
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bias_l + 32 * w + 8 * g + 4 * h);
+            for (int b = 0; b < 2; ++b) {
+                acc[b][4 * g + 0] = bv.x; acc[b][4 * g + 1] = bv.y; acc[b][4 * g + 2] = bv.z; acc[b][4 * g + 3] = bv.w;
             }
         }
-        // ---- epilogue: lane = token 32 b + r, registers 4g..4g+3 of tile t = output features n0 + 32 (NT w + t) + 8g + 4h .. +3
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int nw = n0 + 32 * (NT * w + t);
-            uint32_t obits = 0u;  // bit 16 b + i: output (t, b, i) of this lane is non-zero after rounding
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const int64_t tok = tok0 + 32 * b + r;
-                const bool valid = tok < T;
+                const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(xb + (32 * b + r) * row_bytes + (((2 * ks + h) ^ (r & 15)) * 16));
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], bf, acc[b], 0, 0, 0);
+            }
+        }
+        // issue order: B fragments PRE reads ahead of their MFMAs (left alone the compiler keeps two reads in flight, and every MFMA
+        // then waits out an LDS round trip that 8 waves per CU make long)
+        {
+            constexpr int PRE = 8, N = 2 * KS;
+            __builtin_amdgcn_sched_group_barrier(0x100, PRE, 0);
+#pragma unroll
+            for (int i = 0; i < N - PRE; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, PRE, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        WS_STAMP(3);
+        lds_barrier();  // every wave has read its B fragments: the X buffer becomes the staging tile
+        WS_STAMP(4);
+        // ---- epilogue: lane = token 32 b + r, registers 4g..4g+3 = output features n0 + 32 w + 8g + 4h .. +3
+        const int nw = n0 + 32 * w;
+        uint32_t obits = 0u;  // bit 16 b + i: output (b, i) of this lane is non-zero after rounding
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t tok = tok0 + 32 * b + r;
+            const bool valid = tok < T;
+            if (EPI == EPI_RELU_DROPOUT) {
+                // one 32-bit hash per pair of neighbouring columns, 16 bits each (index = element index / 2, the seed's high
+                // word through E.hi_term: the convention of the round-2 kernel)
+                const uint32_t pair0 = (uint32_t)(((uint64_t)(valid ? tok : T - 1) * (uint64_t)E.row_elems + (uint64_t)(nw + 4 * h)) >> 1);
+                for (int i = 0; i < 16; i += 2) {
+                    float a = fmaxf(acc[b][i], 0.f), c = fmaxf(acc[b][i + 1], 0.f);
+                    if (E.thr16) {
+                        uint32_t xh = (pair0 + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2))) * 0x9E3779B1u + E.hi_term;
+                        xh ^= xh >> 16; xh *= 0x7FEB352Du; xh ^= xh >> 15; xh *= 0x846CA68Bu; xh ^= xh >> 16;
+                        a = (xh & 0xFFFFu) >= E.thr16 ? a * E.inv_keep : 0.f;
+                        c = (xh >> 16) >= E.thr16 ? c * E.inv_keep : 0.f;
+                    }
+                    acc[b][i] = a; acc[b][i + 1] = c;
+                }
+            }
+            if (EPI == EPI_MASK_COLSUM) {
+                const uint32_t wbits = bits_in >> (16 * b);
+                for (int i = 0; i < 16; ++i) acc[b][i] = ((wbits >> i) & 1u) ? acc[b][i] * E.inv_keep : 0.f;
+            }
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t lo = pack2(acc[b][4 * g + 0], acc[b][4 * g + 1]), hi = pack2(acc[b][4 * g + 2], acc[b][4 * g + 3]);
                 if (EPI == EPI_RELU_DROPOUT) {
-                    // one 32-bit hash per pair of neighbouring columns, 16 bits each (index = element index / 2, the seed's high
-                    // word through E.hi_term: the convention of the round-2 kernel)
-                    const uint32_t pair0 = (uint32_t)(((uint64_t)(valid ? tok : T - 1) * (uint64_t)E.row_elems + (uint64_t)(nw + 4 * h)) >> 1);
-                    for (int i = 0; i < 16; i += 2) {
-                        float a = fmaxf(acc[t][b][i], 0.f), c = fmaxf(acc[t][b][i + 1], 0.f);
-                        if (E.thr16) {
-                            uint32_t xh = (pair0 + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2))) * 0x9E3779B1u + E.hi_term;
-                            xh ^= xh >> 16; xh *= 0x7FEB352Du; xh ^= xh >> 15; xh *= 0x846CA68Bu; xh ^= xh >> 16;
-                            a = (xh & 0xFFFFu) >= E.thr16 ? a * E.inv_keep : 0.f;
-                            c = (xh >> 16) >= E.thr16 ? c * E.inv_keep : 0.f;
-                        }
-                        acc[t][b][i] = a; acc[t][b][i + 1] = c;
-                    }
+                    const uint32_t nz = ((lo & 0x7FFFu) ? 1u : 0u) | ((lo & 0x7FFF0000u) ? 2u : 0u) | ((hi & 0x7FFFu) ? 4u : 0u) |
+                                        ((hi & 0x7FFF0000u) ? 8u : 0u);
+                    obits |= nz << (16 * b + 4 * g);
                 }
-                if (EPI == EPI_MASK_COLSUM) {
-                    const uint32_t wbits = bits_in[t] >> (16 * b);
-                    for (int i = 0; i < 16; ++i) acc[t][b][i] = ((wbits >> i) & 1u) ? acc[t][b][i] * E.inv_keep : 0.f;
+                if (EPI == EPI_MASK_COLSUM && valid) {  // what at::sum over the bf16 tensor would add
+                    colacc[4 * g + 0] += __uint_as_float(lo << 16);
+                    colacc[4 * g + 1] += __uint_as_float(lo & 0xFFFF0000u);
+                    colacc[4 * g + 2] += __uint_as_float(hi << 16);
+                    colacc[4 * g + 3] += __uint_as_float(hi & 0xFFFF0000u);
                 }
-                for (int g = 0; g < 4; ++g) {
-                    const uint32_t lo = pack2(acc[t][b][4 * g + 0], acc[t][b][4 * g + 1]), hi = pack2(acc[t][b][4 * g + 2], acc[t][b][4 * g + 3]);
-                    if (EPI == EPI_RELU_DROPOUT) {
-                        const uint32_t nz = ((lo & 0x7FFFu) ? 1u : 0u) | ((lo & 0x7FFF0000u) ? 2u : 0u) | ((hi & 0x7FFFu) ? 4u : 0u) |
-                                            ((hi & 0x7FFF0000u) ? 8u : 0u);
-                        obits |= nz << (16 * b + 4 * g);
-                    }
-                    if (EPI == EPI_MASK_COLSUM && valid) {  // what at::sum over the bf16 tensor would add
-                        colacc[16 * t + 4 * g + 0] += __uint_as_float(lo << 16);
-                        colacc[16 * t + 4 * g + 1] += __uint_as_float(lo & 0xFFFF0000u);
-                        colacc[16 * t + 4 * g + 2] += __uint_as_float(hi << 16);
-                        colacc[16 * t + 4 * g + 3] += __uint_as_float(hi & 0xFFFF0000u);
-                    }
-                    // staging tile: rows of 2 NSW bytes, 16-byte chunk c of row q at c ^ (q & (CPR_Y - 1)); this piece = half a chunk
-                    const int trow = 32 * b + r, c = 4 * (NT * w + t) + g;
-                    *reinterpret_cast<uint2 *>(stage + trow * (2 * NSW) + ((c ^ (trow & (CPR_Y - 1))) * 16) + 8 * h) = make_uint2(lo, hi);
-                }
+                // staging tile: rows of 2 NSW bytes, 16-byte chunk c of row q at c ^ (q & (CPR_Y - 1)); this piece = half a chunk
+                const int trow = 32 * b + r, c = 4 * w + g;
+                *reinterpret_cast<uint2 *>(xb + trow * (2 * NSW) + ((c ^ (trow & (CPR_Y - 1))) * 16) + 8 * h) = make_uint2(lo, hi);
             }
-            if (EPI == EPI_RELU_DROPOUT && E.bits) bits_ptr(tile)[t] = obits;
         }
-        __syncthreads();  // the output tile is complete (and every wave is done reading the X tile)
-        for (int e = tid; e < TOKW * CPR_Y; e += THREADS) {
-            const int trow = e / CPR_Y, p = e % CPR_Y, c = p ^ (trow & (CPR_Y - 1));
-            if (tok0 + trow < T)
-                *reinterpret_cast<uint4 *>(y + (tok0 + trow) * ldy + n0 + 8 * c) =
-                    *reinterpret_cast<const uint4 *>(stage + trow * (2 * NSW) + p * 16);
+        if (EPI == EPI_RELU_DROPOUT && E.bits) bits_ptr(tile)[tid] = obits;
+        WS_STAMP(5);
+        lds_barrier();  // the output tile is complete
+        WS_STAMP(6);
+        if (w >= FETCHERS && w < FETCHERS + WAVES / 2) {  // the storing waves: full row segments, 16 bytes per lane
+            constexpr int PIECES = TOKW * CPR_Y, STORERS = 64 * (WAVES / 2), ROUNDS = PIECES / STORERS;
+            static_assert(PIECES % STORERS == 0, "every storing lane moves the same number of 16-byte pieces");
+            const int e0 = tid - 64 * FETCHERS;
+            uint4 v[ROUNDS];
+#pragma unroll
+            for (int i = 0; i < ROUNDS; ++i) {  // all LDS reads first, then the stores
+                const int e = e0 + STORERS * i;
+                v[i] = *reinterpret_cast<const uint4 *>(xb + (e / CPR_Y) * (2 * NSW) + (e % CPR_Y) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < ROUNDS; ++i) {
+                const int e = e0 + STORERS * i;
+                const int trow = e / CPR_Y, p = e % CPR_Y, c = p ^ (trow & (CPR_Y - 1));
+                if (tok0 + trow < T) *reinterpret_cast<uint4 *>(y + (tok0 + trow) * ldy + n0 + 8 * c) = v[i];
+            }
         }
-        // (the next iteration's barrier separates these reads of the staging tile from the next epilogue's writes)
+        WS_STAMP(7);
+        // (the next iteration's barrier separates these reads of the staging tile from the fetch of tile i + 2 into this buffer)
     }
+#ifdef G2048_WS_STAMPS
+    stamps.flush(lane, w);
+#endif
     if (EPI == EPI_MASK_COLSUM) {
-        // column sums: register q of tile t of lane (r, h) = output feature n0 + 32 (NT w + t) + rowof(q, h) over this lane's tokens
-        for (int t = 0; t < NT; ++t)
-            for (int q = 0; q < 16; ++q) {
-                float v = colacc[16 * t + q];
-                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-                if (r == 0) E.partial[(int64_t)blockIdx.x * E.N + n0 + 32 * (NT * w + t) + rowof(q, h)] = v;
-            }
+        // column sums: register q of lane (r, h) = output feature n0 + 32 w + rowof(q, h) over this lane's tokens
+        for (int q = 0; q < 16; ++q) {
+            float v = colacc[q];
+            for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+            if (r == 0) E.partial[(int64_t)blockIdx.x * E.N + n0 + 32 * w + rowof(q, h)] = v;
+        }
     }
 }
 
@@ -360,9 +496,11 @@ namespace {
 // x + y * groups and the dispatcher deals linear ids round-robin over the 8 XCDs, so the N-slices y of one token tile x share an XCD
 // (and its L2 copy of the X rows) only if groups % 8 == 0.  Measured in round 2 with N = 768 (groups 85): 98.8 MB of HBM reads per
 // launch for a 17.8 MB X (rocprofv3 FETCH_SIZE).
-inline int64_t ws_groups(int64_t T, int N, int NT = 1) {
+inline int ws_waves(int N) { return N % 256 == 0 ? 8 : 4; }
+inline int64_t ws_groups(int64_t T, int N) {
+    const int waves = ws_waves(N);
     const int64_t n_tiles = (T + TOKW - 1) / TOKW;
-    int64_t groups = 512 / (N / (NS * NT));
+    int64_t groups = (waves == 4 ? 512 : 256) / (N / (32 * waves));
     if (groups < 1) groups = 1;
     if (groups >= 8) groups -= groups % 8;
     return groups > n_tiles ? n_tiles : groups;
@@ -374,30 +512,33 @@ inline bool operands_ok(const void *x, int64_t ldx, const void *weight, int64_t 
            !(ldx & 7) && !(ldw & 7) && !(ldy & 7) && !(((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)bias) & 15);
 }
 
-// K <= 256: weights-stationary kernel, two workgroups per CU on 256 CUs shared between the N-slices
-template <bool HAS_BIAS, int EPI, int NT = 1>
-int launch_ws(const __bf16 *x, int64_t ldx, const __bf16 *w, int64_t ldw, const float *bias, __bf16 *y, int64_t ldy, int64_t T, int K,
-              int N, const Epi &E, int *groups_out, hipStream_t stream) {
-    const void *fn = reinterpret_cast<const void *>(k_linear_ws<HAS_BIAS, EPI, NT>);
-    // one 64-token tile of X (K <= 256: 32 KiB) + the output staging tile (16 KiB per 128 outputs): 48 / 64 KiB, two workgroups per CU
-    const int lds_max = TOKW * 256 * 2 + TOKW * NS * NT * 2 + NS * NT * 4;
+// K <= 256: weights-stationary kernel; 256-wide slices (8 waves, one workgroup per CU) when N allows, else 128-wide (4 waves, two per CU)
+template <bool HAS_BIAS, int EPI, int KS, int WAVES>
+int launch_ws(const __bf16 *x, int64_t ldx, const __bf16 *w, int64_t ldw, const float *bias, __bf16 *y, int64_t ldy, int64_t T, int N,
+              const Epi &E, int64_t groups, hipStream_t stream) {
+    const void *fn = reinterpret_cast<const void *>(k_linear_ws<HAS_BIAS, EPI, KS, WAVES>);
+    // the X buffers (the consumed one doubles as the output staging tile) + bias + mask words
+    const int nb = 2;
+    const int lds = nb * ws_xbytes(16 * KS, WAVES) + 32 * WAVES * 4 + nb * 64 * WAVES * 4;
     // the dynamic-LDS limit is a per-device attribute of the one kernel this call launches: set per call, no latch
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) return -(1000 + (int)hipGetLastError());
-    const int64_t n_tiles = (T + TOKW - 1) / TOKW;
-    const int slices = N / (NS * NT);
-    int64_t groups = ws_groups(T, N, NT);
-    if (groups_out) *groups_out = (int)groups;
-    (void)n_tiles;
-    const int lds = TOKW * K * 2 + TOKW * NS * NT * 2 + NS * NT * 4;
-    hipLaunchKernelGGL((k_linear_ws<HAS_BIAS, EPI, NT>), dim3((unsigned)groups, (unsigned)slices), dim3(THREADS), lds, stream, x, ldx, w,
-                       ldw, bias, y, ldy, T, K, E);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -(1000 + (int)hipGetLastError());
+    hipLaunchKernelGGL((k_linear_ws<HAS_BIAS, EPI, KS, WAVES>), dim3((unsigned)groups, (unsigned)(N / (32 * WAVES))), dim3(64 * WAVES), lds,
+                       stream, x, ldx, w, ldw, bias, y, ldy, T, E);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }
 template <bool HAS_BIAS, int EPI>
 int launch_stationary(const __bf16 *x, int64_t ldx, const __bf16 *w, int64_t ldw, const float *bias, __bf16 *y, int64_t ldy, int64_t T,
                       int K, int N, const Epi &E, int *groups_out, hipStream_t stream) {
-    return launch_ws<HAS_BIAS, EPI>(x, ldx, w, ldw, bias, y, ldy, T, K, N, E, groups_out, stream);
+    if (K != 256 && K != 128) return G2048_EINVAL;
+    const int64_t groups = ws_groups(T, N);
+    if (groups_out) *groups_out = (int)groups;
+    const bool wide = ws_waves(N) == 8;
+    if (K == 256)
+        return wide ? launch_ws<HAS_BIAS, EPI, 16, 8>(x, ldx, w, ldw, bias, y, ldy, T, N, E, groups, stream)
+                    : launch_ws<HAS_BIAS, EPI, 16, 4>(x, ldx, w, ldw, bias, y, ldy, T, N, E, groups, stream);
+    return wide ? launch_ws<HAS_BIAS, EPI, 8, 8>(x, ldx, w, ldw, bias, y, ldy, T, N, E, groups, stream)
+                : launch_ws<HAS_BIAS, EPI, 8, 4>(x, ldx, w, ldw, bias, y, ldy, T, N, E, groups, stream);
 }
 
 }  // namespace
@@ -473,3 +614,14 @@ extern "C" int g2048_linear_mask_bwd_bf16(const void *dy, int64_t lddy, const vo
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }
+
+#ifdef G2048_WS_STAMPS
+extern "C" int g2048_debug_ws_stamps(unsigned long long *out /*host [2][8]*/, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_stamps), sizeof(g_ws_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        static const unsigned long long zero[2][WS_PHASES] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ws_stamps), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
