@@ -218,35 +218,35 @@ __device__ __forceinline__ void dma_async16(const void *sbase, uint32_t voff, vo
 #pragma clang diagnostic pop
 
 // X tile [64 tokens][K] -> LDS rows of K * 2 bytes, chunk q of row r at q ^ (r & 15); K = 256: 32 wave-instructions of 1 KiB (2 rows
-// each), dealt to the FETCHERS fetching waves (see k_linear_ws): wave f issues instructions f, f + FETCHERS, ...
+// each), dealt to the workgroup's NF waves: wave f issues instructions f, f + NF, ...
 constexpr int TOKW = 64;  // tokens per tile of k_linear_ws
-constexpr int FETCHERS = 2;
 // one X buffer of k_linear_ws: the 64-token tile, or the output staging tile it turns into (64 rows of the slice), whichever is larger
 __host__ __device__ constexpr int ws_xbytes(int K, int waves) { return TOKW * 2 * (K > 32 * waves ? K : 32 * waves); }
-template <int K>
+template <int K, int NF>
 struct XTileDma {
     static constexpr int CPR = K / 8, RPI = 64 / CPR, N_INST = TOKW / RPI;  // 16-byte chunks per row, rows per instruction
-    static constexpr int NVAR = 16 / RPI / FETCHERS;                         // distinct swizzles among ONE fetcher's instructions
+    static constexpr int NVAR = 16 / RPI / NF > 0 ? 16 / RPI / NF : 1;       // distinct swizzles among ONE wave's instructions
+    static_assert(N_INST % NF == 0, "every wave issues the same number of fetch instructions");
     uint32_t voff[NVAR];  // per-lane byte offset of this fetcher's instruction j (j % NVAR decides the swizzle): lane's row * ldx * 2 + 16 q
     int sub, p;
     __device__ __forceinline__ void init(int64_t ldx, int lane, int f) {
         sub = lane / CPR, p = lane % CPR;
         for (int v = 0; v < NVAR; ++v)
-            voff[v] = (uint32_t)(sub * ldx * 2) + 16u * (uint32_t)(p ^ ((RPI * (FETCHERS * v + f) + sub) & 15));
+            voff[v] = (uint32_t)(sub * ldx * 2) + 16u * (uint32_t)(p ^ ((RPI * (NF * v + f) + sub) & 15));
     }
     // whole tile inside [0, T): scalar row base per instruction, nothing on the vector ALU
     __device__ __forceinline__ void full(char *dst, const __bf16 *x, int64_t ldx, int64_t tok0, int f) const {
         const char *base = reinterpret_cast<const char *>(x + tok0 * ldx);
 #pragma unroll
-        for (int j = 0; j < N_INST / FETCHERS; ++j) {
-            const int n = FETCHERS * j + f;
+        for (int j = 0; j < N_INST / NF; ++j) {
+            const int n = NF * j + f;
             dma_async16(base + (int64_t)n * RPI * ldx * 2, voff[j % NVAR], dst + n * 1024);
         }
     }
     // last, partial tile: rows past T read row T - 1 (computed and not stored)
     __device__ __forceinline__ void clamped(char *dst, const __bf16 *x, int64_t ldx, int64_t tok0, int64_t T, int f) const {
-        for (int j = 0; j < N_INST / FETCHERS; ++j) {
-            const int n = FETCHERS * j + f;
+        for (int j = 0; j < N_INST / NF; ++j) {
+            const int n = NF * j + f;
             const int row = n * RPI + sub;
             int64_t tok = tok0 + row;
             if (tok >= T) tok = T - 1;
@@ -256,7 +256,7 @@ struct XTileDma {
 };
 
 // Diagnostic build only (-DG2048_WS_STAMPS, tools/stamps_linear.py; never compiled into the product library): cycle stamps at the phase
-// boundaries of k_linear_ws, summed per phase by one fetching and one storing wave of every 16th workgroup row of slice 0.
+// boundaries of k_linear_ws, summed per phase by waves 0 and 1 of every 16th workgroup row of slice 0.
 #ifdef G2048_WS_STAMPS
 constexpr int WS_PHASES = 8;
 __device__ unsigned long long g_ws_stamps[2][WS_PHASES];
@@ -279,7 +279,7 @@ struct WsStamps {
         last = t;
     }
     __device__ __forceinline__ void flush(int lane, int w) {
-        if (lane == 0 && (w == 0 || w == FETCHERS) && blockIdx.y == 0 && blockIdx.x % 16 == 0)
+        if (lane == 0 && w < 2 && blockIdx.y == 0 && blockIdx.x % 16 == 0)
             for (int i = 0; i < WS_PHASES; ++i) atomicAdd(&g_ws_stamps[w == 0 ? 0 : 1][i], acc[i]);
     }
 };
@@ -292,17 +292,32 @@ struct WsStamps {
 // wait for their global stores at every barrier
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Roles inside the workgroup (round 3, second form).  A wave's vmcnt counts loads AND stores and is waited for in order, so a wave
-// that both fetches tile i + 1 and stores tile i cannot wait for the one without the other (measured: double buffering with every wave
-// doing both changed nothing).  Here waves 0..1 issue ALL LDS-DMA fetches (X tile, mask words) and never store the output tile; waves
-// 2..3 copy the staged output tile to global memory and never wait on vmcnt at all.  X is double buffered: the fetch of tile i + 1 is
-// issued right after the barrier that publishes tile i and has the whole tile (MFMAs, epilogue, copy-out) to land.  The output is
-// staged in the X buffer it was computed from (one more barrier), so a workgroup needs 2 x 32 KiB + 2.5 KiB: two workgroups per CU.
-// WAVES = 4: a 128-wide slice of N per workgroup, two workgroups per CU; WAVES = 8: a 256-wide slice, one workgroup per CU - the X tile
-// is fetched once per 256 outputs.  What bounds the kernel is the CU's vector-memory path (one texture addresser per CU: ~45-60 cycles
-// per 1 KiB wave-instruction, LDS-DMA fetches and stores alike; `TA_TA_BUSY` 40 % while the L2 -> memory write path stalls 2 % of its
-// cycles, profiles/round3_linear_ws_mem_pmc.json): per 128 outputs and tile 32 fetch + 16 store instructions with WAVES = 4, 16 + 16
-// with WAVES = 8.
+// The loop of a workgroup over its 64-token tiles (round 3, final form).  A wave's vmcnt counts loads AND stores, so "wait for my
+// fetch" right after "store my share of the previous tile" waits for the stores too (measured: double buffering with the wait at the top
+// of the tile changed nothing).  The order that avoids it - every wave does the same:
+//   barrier 1                      tile i is in X buffer p (published by barrier 3 of the previous tile)
+//   issue my fetch instructions of tile i + 1 into buffer p ^ 1 (LDS-DMA: X rows, mask words)
+//   bias -> accumulators, 2 KS MFMAs against buffer p (B fragments 8 reads ahead)
+//   barrier 2                      every wave has read its fragments: buffer p becomes the output staging tile
+//   epilogue -> staging tile
+//   s_waitcnt vmcnt(0)             my fetch (issued ~2 000 cycles ago) AND my stores of tile i - 1 (~3 000 cycles ago): both old
+//   barrier 3                      staging tile complete, tile i + 1 published
+//   copy my share of the staging tile to global memory: full row segments, 16 bytes per lane; never waited for here
+// Forms measured on the way (N = 1024, tools/stamps_linear.py for the cycles per tile):
+//   * dedicated fetching (2) and storing (2..4) waves: the coupling is gone as well, but a wave issues one 1 KiB vector-memory
+//     instruction per ~60 cycles (eight waves together one per ~20), so the 1 000 cycles of fetch issue and the 1 500 of copy-out of those
+//     few waves sat on the tile's critical path: 28.2-28.9 us, the same as this form, with more code;
+//   * the same with a third X buffer and the fetch issued while the storing waves copy out: 30.3 us (fetches and stores contend for
+//     the CU's one texture addresser; overlapping them makes both slower);
+//   * a private staging tile per wave and ONE barrier per tile, so that the waves of a SIMD drift apart and one's MFMAs run under the
+//     other's epilogue: 39.8 us - the 64-byte row segments a single wave can store are half cache lines.
+// What is left (stamps): of ~5 250 cycles per tile the MFMA phase takes 2 170 for 1 024 cycles of MFMA per wave - both waves of a SIMD
+// are in it at the same time and the matrix pipe idles through the other phases (epilogue 630, copy-out 750, fetch issue 450, three
+// barriers 1 170).  Two independent workgroups per CU would interleave the phases, but need <= 128 registers per wave; the weight
+// tile alone is 64.
+// WAVES = 8: a 256-wide slice of N per workgroup, one workgroup per CU - the X tile goes through the CU's vector-memory path once per
+// 256 outputs instead of once per 128 (30.9 -> 28.9 us); WAVES = 4: 128-wide, two workgroups per CU, for widths that are not
+// multiples of 256.
 template <bool HAS_BIAS, int EPI, int KS, int WAVES>  // KS = K / 16: 16 (K = 256) or 8 (K = 128)
 __global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1)
 k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ wgt, int64_t ldw, const float *__restrict__ bias,
@@ -347,19 +362,18 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
     auto bits_ptr = [&](int64_t tile) -> uint32_t * {
         return reinterpret_cast<uint32_t *>(E.bits) + (tile * slices + blockIdx.y) * THREADS;
     };
-    XTileDma<K> dma;
+    XTileDma<K, WAVES> dma;
     dma.init(ldx, lane, w);
-    auto fetch = [&](int64_t tile, int buf) {  // fetching waves only (w < FETCHERS)
+    auto fetch = [&](int64_t tile, int buf) {  // this wave's share
         if ((tile + 1) * TOKW <= T) dma.full(smem + buf * xbytes, x, ldx, tile * TOKW, w);
         else dma.clamped(smem + buf * xbytes, x, ldx, tile * TOKW, T, w);
         if (EPI == EPI_MASK_COLSUM) {
             const uint32_t *g = bits_ptr(tile) + lane;
-#pragma unroll
-            for (int j = w; j < THREADS / 64; j += FETCHERS) dma_async<4>(g + 64 * j, bits_l + buf * THREADS + 64 * j);
+            dma_async<4>(g + 64 * w, bits_l + buf * THREADS + 64 * w);
         }
     };
-    const bool fetcher = w < FETCHERS;
-    if (fetcher && (int64_t)blockIdx.x < n_tiles64) fetch(blockIdx.x, 0);
+    if ((int64_t)blockIdx.x < n_tiles64) fetch(blockIdx.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the first barrier 1 publishes the first tile)
 #ifdef G2048_WS_STAMPS
     WsStamps stamps;
     stamps.start();
@@ -368,11 +382,9 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
     for (int64_t tile = blockIdx.x; tile < n_tiles64; tile += gridDim.x, buf ^= 1) {
         const int64_t tok0 = tile * TOKW;
         char *const xb = smem + buf * xbytes;
-        if (fetcher) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's fetch (issued a whole tile ago) has landed
-        WS_STAMP(0);
-        lds_barrier();  // ... for every wave; and every wave is done with the other buffer (copy-out of the previous tile)
+        lds_barrier();  // every wave is done with the other buffer (its reads for the copy-out of the previous tile)
         WS_STAMP(1);
-        if (fetcher && tile + gridDim.x < n_tiles64) fetch(tile + gridDim.x, buf ^ 1);
+        if (tile + gridDim.x < n_tiles64) fetch(tile + gridDim.x, buf ^ 1);
         WS_STAMP(2);
         const uint32_t bits_in = EPI == EPI_MASK_COLSUM ? bits_l[buf * THREADS + tid] : 0u;
         f32x16 acc[2];
@@ -453,12 +465,14 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
         }
         if (EPI == EPI_RELU_DROPOUT && E.bits) bits_ptr(tile)[tid] = obits;
         WS_STAMP(5);
-        lds_barrier();  // the output tile is complete
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my part of the next tile has landed; my stores of the previous tile are out
+        WS_STAMP(0);
+        lds_barrier();  // the output tile is complete, the next X tile is published
         WS_STAMP(6);
-        if (w >= FETCHERS && w < FETCHERS + WAVES / 2) {  // the storing waves: full row segments, 16 bytes per lane
-            constexpr int PIECES = TOKW * CPR_Y, STORERS = 64 * (WAVES / 2), ROUNDS = PIECES / STORERS;
-            static_assert(PIECES % STORERS == 0, "every storing lane moves the same number of 16-byte pieces");
-            const int e0 = tid - 64 * FETCHERS;
+        {
+            constexpr int PIECES = TOKW * CPR_Y, STORERS = THREADS, ROUNDS = PIECES / STORERS;
+            static_assert(PIECES % STORERS == 0, "every lane moves the same number of 16-byte pieces");
+            const int e0 = tid;
             uint4 v[ROUNDS];
 #pragma unroll
             for (int i = 0; i < ROUNDS; ++i) {  // all LDS reads first, then the stores

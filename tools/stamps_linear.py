@@ -13,8 +13,8 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 PKG = os.path.join(ROOT, "2048-ppo-agent_amd")
 OUT = os.path.join(ROOT, "tools", "_build", "libg2048_ws_stamps.so")
-NAMES = ["wait for the fetch (vmcnt; fetchers only)", "barrier 1 (tile published)", "issue next fetch", "bias + 32 MFMAs",
-         "barrier 2 (X buffer free)", "epilogue -> staging tile", "barrier 3 (tile staged)", "copy-out (storers only)"]
+NAMES = ["vmcnt(0): next tile's fetch + previous tile's stores", "barrier 1 (other buffer free)", "issue next fetch", "bias + 32 MFMAs",
+         "barrier 2 (X buffer free)", "epilogue -> staging tile", "barrier 3 (tile staged, next published)", "copy-out"]
 
 
 def build():
@@ -59,7 +59,7 @@ if __name__ == "__main__":
     stamped_rows = (groups + 15) // 16
     tiles_seen = n * sum(len(range(g, tiles, groups)) for g in range(0, groups, 16))
     out = {}
-    for role, name in enumerate(("fetching wave", "storing wave")):
+    for role, name in enumerate(("wave 0", "wave 1")):
         v = [int(buf[8 * role + i]) for i in range(8)]
         tot = sum(v)
         print(f"{name}: {tot / tiles_seen:.0f} cycles per tile (s_memtime ticks)")
