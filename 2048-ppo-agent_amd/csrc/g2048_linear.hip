@@ -220,8 +220,6 @@ __device__ __forceinline__ void dma_async16(const void *sbase, uint32_t voff, vo
 // X tile [64 tokens][K] -> LDS rows of K * 2 bytes, chunk q of row r at q ^ (r & 15); K = 256: 32 wave-instructions of 1 KiB (2 rows
 // each), dealt to the workgroup's NF waves: wave f issues instructions f, f + NF, ...
 constexpr int TOKW = 64;  // tokens per tile of k_linear_ws
-// one X buffer of k_linear_ws: the 64-token tile, or the output staging tile it turns into (64 rows of the slice), whichever is larger
-__host__ __device__ constexpr int ws_xbytes(int K, int waves) { return TOKW * 2 * (K > 32 * waves ? K : 32 * waves); }
 template <int K, int NF>
 struct XTileDma {
     static constexpr int CPR = K / 8, RPI = 64 / CPR, N_INST = TOKW / RPI;  // 16-byte chunks per row, rows per instruction
@@ -298,8 +296,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //   barrier 1                      tile i is in X buffer p (published by barrier 3 of the previous tile)
 //   issue my fetch instructions of tile i + 1 into buffer p ^ 1 (LDS-DMA: X rows, mask words)
 //   bias -> accumulators, 2 KS MFMAs against buffer p (B fragments 8 reads ahead)
-//   barrier 2                      every wave has read its fragments: buffer p becomes the output staging tile
-//   epilogue -> staging tile
+//   epilogue -> staging tile (a buffer of its own: with the X buffer doubling as staging tile a third barrier sat here, 29.0 -> 28.0 us)
 //   s_waitcnt vmcnt(0)             my fetch (issued ~2 000 cycles ago) AND my stores of tile i - 1 (~3 000 cycles ago): both old
 //   barrier 3                      staging tile complete, tile i + 1 published
 //   copy my share of the staging tile to global memory: full row segments, 16 bytes per lane; never waited for here
@@ -311,15 +308,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //     the CU's one texture addresser; overlapping them makes both slower);
 //   * a private staging tile per wave and ONE barrier per tile, so that the waves of a SIMD drift apart and one's MFMAs run under the
 //     other's epilogue: 39.8 us - the 64-byte row segments a single wave can store are half cache lines.
-// What is left (stamps): of ~5 250 cycles per tile the MFMA phase takes 2 170 for 1 024 cycles of MFMA per wave - both waves of a SIMD
-// are in it at the same time and the matrix pipe idles through the other phases (epilogue 630, copy-out 750, fetch issue 450, three
-// barriers 1 170).  Two independent workgroups per CU would interleave the phases, but need <= 128 registers per wave; the weight
-// tile alone is 64.
-// WAVES = 8: a 256-wide slice of N per workgroup, one workgroup per CU - the X tile goes through the CU's vector-memory path once per
-// 256 outputs instead of once per 128 (30.9 -> 28.9 us); WAVES = 4: 128-wide, two workgroups per CU, for widths that are not
-// multiples of 256.
+// What is left (stamps): of ~5 000 cycles per tile the MFMA phase takes 2 170 for 1 024 cycles of MFMA per wave - both waves of a SIMD
+// are in it at the same time and the matrix pipe idles through the other phases (epilogue 630, copy-out 750, fetch issue 450,
+// barriers ~900).  Running token block 0's epilogue in the shadow of block 1's MFMAs was tried with sched_group_barrier masks: the
+// solver dropped the whole pipeline (ds_read -> wait -> MFMA, no prefetch); it would take the hand-cut steps of the rollout encoder.
+// Two independent workgroups per CU would interleave the phases, but need <= 128 registers per wave; the weight tile alone is 64.
+// WAVES = 8: a 256-wide slice of N per workgroup - the X tile goes through the CU's vector-memory path once per 256 outputs instead of
+// once per 128 (30.9 -> 28.9 us); WAVES = 4: 128-wide, for widths that are not multiples of 256.  One workgroup per CU either way.
 template <bool HAS_BIAS, int EPI, int KS, int WAVES>  // KS = K / 16: 16 (K = 256) or 8 (K = 128)
-__global__ void __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1)
+__global__ void __launch_bounds__(64 * WAVES, 1)
 k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ wgt, int64_t ldw, const float *__restrict__ bias,
             __bf16 *__restrict__ y, int64_t ldy, int64_t T, Epi E) {
     constexpr int THREADS = 64 * WAVES, NSW = 32 * WAVES;  // slice width
@@ -329,7 +326,7 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.y * NSW;
-    constexpr int row_bytes = K * 2, xbytes = ws_xbytes(K, WAVES);
+    constexpr int row_bytes = K * 2, xbytes = TOKW * row_bytes, sbytes = TOKW * 2 * NSW;
 
     // ---- this wave's weight tile: rows n0 + 32 w .. + 31, all of K (fragment ks = columns 16 ks + 8 h .. + 7 of row .. + r)
     bf16x8 wf[KS];
@@ -342,9 +339,11 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
     // storing waves copy tile i out - with a third buffer to keep the lead - measured SLOWER, 30.3 vs 28.5 us at N = 1024: fetches and
     // stores go through the same texture addresser, and it is what bounds the kernel; overlapping them only makes both slower.)
     constexpr int NB = 2;
-    // LDS: the X buffers, the slice's bias (it enters through the accumulators' initial value, 4 broadcast reads per tile), mask words
-    float *const bias_l = reinterpret_cast<float *>(smem + NB * xbytes);
-    uint32_t *const bits_l = reinterpret_cast<uint32_t *>(smem + NB * xbytes + NSW * 4);  // [NB][THREADS]
+    // LDS: the X buffers, the output staging tile, the slice's bias (it enters through the accumulators' initial value, 4 broadcast
+    // reads per tile), mask words
+    char *const stage = smem + NB * xbytes;
+    float *const bias_l = reinterpret_cast<float *>(smem + NB * xbytes + sbytes);
+    uint32_t *const bits_l = reinterpret_cast<uint32_t *>(smem + NB * xbytes + sbytes + NSW * 4);  // [NB][THREADS]
     for (int i = tid; i < NSW; i += THREADS) bias_l[i] = HAS_BIAS ? bias[n0 + i] : 0.f;
     if (EPI == EPI_RELU_DROPOUT) {
         if (E.seed_state) {
@@ -381,8 +380,8 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
     int buf = 0;
     for (int64_t tile = blockIdx.x; tile < n_tiles64; tile += gridDim.x, buf ^= 1) {
         const int64_t tok0 = tile * TOKW;
-        char *const xb = smem + buf * xbytes;
-        lds_barrier();  // every wave is done with the other buffer (its reads for the copy-out of the previous tile)
+        const char *const xb = smem + buf * xbytes;
+        lds_barrier();  // every wave is done with the staging tile (its reads for the copy-out of the previous tile)
         WS_STAMP(1);
         if (tile + gridDim.x < n_tiles64) fetch(tile + gridDim.x, buf ^ 1);
         WS_STAMP(2);
@@ -417,8 +416,6 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
         }
         __builtin_amdgcn_sched_barrier(0);
         WS_STAMP(3);
-        lds_barrier();  // every wave has read its B fragments: the X buffer becomes the staging tile
-        WS_STAMP(4);
         // ---- epilogue: lane = token 32 b + r, registers 4g..4g+3 = output features n0 + 32 w + 8g + 4h .. +3
         const int nw = n0 + 32 * w;
         uint32_t obits = 0u;  // bit 16 b + i: output (b, i) of this lane is non-zero after rounding
@@ -460,7 +457,7 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
                 }
                 // staging tile: rows of 2 NSW bytes, 16-byte chunk c of row q at c ^ (q & (CPR_Y - 1)); this piece = half a chunk
                 const int trow = 32 * b + r, c = 4 * w + g;
-                *reinterpret_cast<uint2 *>(xb + trow * (2 * NSW) + ((c ^ (trow & (CPR_Y - 1))) * 16) + 8 * h) = make_uint2(lo, hi);
+                *reinterpret_cast<uint2 *>(stage + trow * (2 * NSW) + ((c ^ (trow & (CPR_Y - 1))) * 16) + 8 * h) = make_uint2(lo, hi);
             }
         }
         if (EPI == EPI_RELU_DROPOUT && E.bits) bits_ptr(tile)[tid] = obits;
@@ -477,7 +474,7 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
 #pragma unroll
             for (int i = 0; i < ROUNDS; ++i) {  // all LDS reads first, then the stores
                 const int e = e0 + STORERS * i;
-                v[i] = *reinterpret_cast<const uint4 *>(xb + (e / CPR_Y) * (2 * NSW) + (e % CPR_Y) * 16);
+                v[i] = *reinterpret_cast<const uint4 *>(stage + (e / CPR_Y) * (2 * NSW) + (e % CPR_Y) * 16);
             }
 #pragma unroll
             for (int i = 0; i < ROUNDS; ++i) {
@@ -514,7 +511,7 @@ inline int ws_waves(int N) { return N % 256 == 0 ? 8 : 4; }
 inline int64_t ws_groups(int64_t T, int N) {
     const int waves = ws_waves(N);
     const int64_t n_tiles = (T + TOKW - 1) / TOKW;
-    int64_t groups = (waves == 4 ? 512 : 256) / (N / (32 * waves));
+    int64_t groups = 256 / (N / (32 * waves));
     if (groups < 1) groups = 1;
     if (groups >= 8) groups -= groups % 8;
     return groups > n_tiles ? n_tiles : groups;
@@ -531,9 +528,8 @@ template <bool HAS_BIAS, int EPI, int KS, int WAVES>
 int launch_ws(const __bf16 *x, int64_t ldx, const __bf16 *w, int64_t ldw, const float *bias, __bf16 *y, int64_t ldy, int64_t T, int N,
               const Epi &E, int64_t groups, hipStream_t stream) {
     const void *fn = reinterpret_cast<const void *>(k_linear_ws<HAS_BIAS, EPI, KS, WAVES>);
-    // the X buffers (the consumed one doubles as the output staging tile) + bias + mask words
-    const int nb = 2;
-    const int lds = nb * ws_xbytes(16 * KS, WAVES) + 32 * WAVES * 4 + nb * 64 * WAVES * 4;
+    // two X buffers + the output staging tile + bias + mask words
+    const int lds = 2 * TOKW * 16 * KS * 2 + TOKW * 2 * 32 * WAVES + 32 * WAVES * 4 + 2 * 64 * WAVES * 4;
     // the dynamic-LDS limit is a per-device attribute of the one kernel this call launches: set per call, no latch
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -(1000 + (int)hipGetLastError());
     hipLaunchKernelGGL((k_linear_ws<HAS_BIAS, EPI, KS, WAVES>), dim3((unsigned)groups, (unsigned)(N / (32 * WAVES))), dim3(64 * WAVES), lds,
