@@ -77,6 +77,7 @@ SIGNATURES = {
     "g2048_cls_tail_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_cls_tail_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_dweight_t": [_vp, _i32, _i64, _i64, _i32, _vp],
+    "g2048_dweight_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "g2048_opt_workspace_floats": [_i32],
     "g2048_opt_step": [_vp, _i32, _vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _i32, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp, _vp],
 }
@@ -758,6 +759,30 @@ def cls_tail_bwd(dlogits, dvalues, WT: TailWeightsT, buf: TailBuffers, p_drop: f
                                      C.byref(buf.saved_c), C.byref(buf.grads_c), buf.d_o.data_ptr(), buf.dx_cls.data_ptr(), buf.M,
                                      float(p_drop), int(seed), seed_state or None, _stream()), "g2048_cls_tail_bwd")
     return buf.d_o, buf.dx_cls
+
+
+def dweight_ok(dy2: torch.Tensor, x2: torch.Tensor, slices: int) -> bool:
+    """Operands ``g2048_dweight_bf16`` takes: bf16 [T, N] / [T, K] row views (unit inner stride), N and K multiples of 128,
+    T a multiple of 64 * slices."""
+    if dy2.dim() != 2 or x2.dim() != 2 or dy2.shape[0] != x2.shape[0]:
+        return False
+    T, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
+    for t in (dy2, x2):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16 or t.stride(0) >= 1 << 27:
+            return False
+    return N % 128 == 0 and K % 128 == 0 and T > 0 and T % (64 * slices) == 0 and (slices < 8 or slices % 8 == 0)
+
+
+def dweight_parts(dy2: torch.Tensor, x2: torch.Tensor, slices: int, out: torch.Tensor = None, block_rows: int = 0) -> torch.Tensor:
+    """bf16 [slices, N, K] whose sum over the first axis is dY^T X (``g2048_dweight_bf16``)."""
+    if not dweight_ok(dy2, x2, slices):
+        raise NativeError(f"dweight_parts: operands {tuple(dy2.shape)} x {tuple(x2.shape)} with {slices} slices are not supported")
+    T, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
+    if out is None:
+        out = torch.empty((slices, N, K), dtype=torch.bfloat16, device=dy2.device)
+    _check(load().g2048_dweight_bf16(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), _dev(out, torch.bfloat16, slices * N * K, "parts"),
+                                     T, N, K, int(slices), int(block_rows), _stream()), "g2048_dweight_bf16")
+    return out
 
 
 def dweight_t(jobs, ld: int, m: int, slices: int):

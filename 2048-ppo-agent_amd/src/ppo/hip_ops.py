@@ -247,6 +247,12 @@ def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """The first stage of ``_dweight``: bf16 [parts, out, in] whose sum over parts is dW (parts = 16 split-K slices for a
     long token axis, else 1)."""
     T, S = x2.shape[0], _SINK_SLICES
+    if T >= 16384:  # the minibatch's token axis: g2048_dweight_bf16, [128 x 128] blocks x slices = 128-256 workgroups
+        from ..g2048 import native as nv
+
+        slices = 16 if dy2.shape[1] * x2.shape[1] > 256 * 256 else 32
+        if nv.dweight_ok(dy2, x2, slices):
+            return nv.dweight_parts(dy2, x2, slices, block_rows=128)
     # also for the 2048-row GEMMs of the CLS-only layer and the heads: their [out, in] results are a handful of tiles with a
     # 2048-long reduction each (17 us per GEMM in the pipeline); the sink adds the slices at no extra launch
     if T % S == 0 and T // S >= 64:

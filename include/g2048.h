@@ -274,6 +274,18 @@ int64_t g2048_relu_dropout_bwd_workspace_floats(int64_t T, int F);
 int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias, float *workspace, int64_t T, int F,
                            float p_drop, void *stream);
 
+/* ---- policy network (update): weight gradient of a Linear over the whole minibatch ------------------------------ */
+
+/* parts[s][n][k] = sum over the tokens t of slice s (T / slices consecutive rows) of dy[t][n] * x[t][k]: the first stage of
+ * dW = dY^T X for an nn.Linear applied to T token rows (reference: autograd of the Linears of nn.TransformerEncoderLayer,
+ * src/ppo/transformer_encoder.py:138-148, inside PPOTrainer.update_policy, src/ppo/ppo_trainer.py:409-437); the sum over s is
+ * left to g2048_reduce_jobs.  dy bf16 [T][N] and x bf16 [T][K] with leading dimensions lddy / ldx (elements, multiples of 8),
+ * parts bf16 [slices][N][K] contiguous; N and K multiples of 128, T a multiple of 64 * slices, slices 1..7 or a multiple of
+ * 8; base pointers 16-byte aligned.  f32 accumulation over a slice, one rounding to bf16 per partial.  block_rows: rows of the
+ * gradient per workgroup (x 128 columns), 128 or 256 (N a multiple of 256), 0 = the kernel's choice; slices x blocks workgroups. */
+int g2048_dweight_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, void *parts, int64_t T, int N, int K,
+                       int slices, int block_rows, void *stream);
+
 /* ---- policy network (update): Linear for tall-skinny activations ------------------------------------------ */
 
 /* y[T][N] = x[T][K] . weight[N][K]^T (+ bias[N]) - nn.Linear in bf16 with f32 accumulation (reference: every nn.Linear

@@ -673,7 +673,7 @@ def test_fused_ffn_kernels(dev):
     torch.manual_seed(23)
     rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
     for T in (1, 130, 4096, 34816 + 3):
-        for K, N in ((256, 1024), (256, 512), (128, 128)):
+        for K, N in ((256, 1024), (256, 512), (128, 128), (256, 384)):  # 256-wide slices (8 waves) and 128-wide (4 waves)
             x = torch.randn(T, K, device=dev).to(torch.bfloat16)
             w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
             b = 0.2 * torch.randn(N, device=dev)
@@ -758,7 +758,7 @@ def test_linked_ffn_block_matches_torch(dev):
 
 
 def test_linear_bf16_matches_torch(dev):
-    """g2048_linear_bf16 (MFMA, weights streamed through LDS) vs an f32 reference: as close as hipBLASLt's bf16 GEMM,
+    """g2048_linear_bf16 (MFMA; K <= 256: weights in registers, X through LDS; K > 256: weights streamed through LDS) vs an f32 reference: as close as hipBLASLt's bf16 GEMM,
     ragged T, all (K, N) of the update, strided inputs/weights (views), with and without bias."""
     import torch.nn.functional as F
 
@@ -767,7 +767,7 @@ def test_linear_bf16_matches_torch(dev):
     torch.manual_seed(13)
     rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
     for T in (1, 31, 128, 129, 2048, 34816 + 5):
-        for K, N in ((256, 256), (256, 768), (256, 1024), (1024, 256), (768, 256), (128, 128), (512, 384)):
+        for K, N in ((256, 256), (256, 768), (256, 1024), (1024, 256), (768, 256), (128, 128), (512, 384), (256, 384), (128, 256)):
             x = torch.randn(T, K, device=dev).to(torch.bfloat16)
             w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
             b = torch.randn(N, device=dev)
@@ -1014,3 +1014,40 @@ def test_no_garbage_collection_while_a_stream_is_capturing(dev, tmp_path, monkey
         assert seen.total > 0 and seen.during_capture == 0
     finally:
         gc.set_threshold(*old)
+
+
+def test_dweight_parts_match_f32_reference(dev):
+    """g2048_dweight_bf16 (token-major operands staged by LDS-DMA, transposed MFMA operand reads): the sum of the partials against
+    dY^T X in f32 - as close as the batched hipBLASLt GEMM it replaces -, every (N, K) of the update + the 128-wide block shape,
+    1 / 8 / 16 / 32 slices, column-slice views as operands, and the refusals."""
+    from src.g2048 import native as nv
+
+    torch.manual_seed(41)
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    for T, S in ((64, 1), (1024, 8), (34816, 16), (34816, 32)):
+        for N, K in ((1024, 256), (256, 1024), (768, 256), (256, 256), (128, 128), (384, 128)):
+            if T * N * K > 34816 * 1024 * 256 // 2 and S == 32 and (N, K) != (1024, 256):
+                continue  # one full-size case per slice count is enough
+            dy = (torch.randn(T, N, device=dev) / 8).to(torch.bfloat16)
+            x = torch.randn(T, K, device=dev).to(torch.bfloat16)
+            parts = nv.dweight_parts(dy, x, S)
+            assert parts.shape == (S, N, K) and parts.dtype == torch.bfloat16
+            ref = dy.float().t() @ x.float()
+            assert rel(parts.float().sum(0), ref) < 4e-3, (T, S, N, K, rel(parts.float().sum(0), ref))
+            # every partial is the product over its own token slice
+            s = S // 2
+            rows = slice(s * (T // S), (s + 1) * (T // S))
+            assert rel(parts[s], dy[rows].float().t() @ x[rows].float()) < 4e-3
+            assert torch.equal(parts, nv.dweight_parts(dy, x, S))  # fixed summation order
+            if N % 256 == 0 and T <= 1024:  # both block shapes
+                for rows in (128, 256):
+                    assert rel(nv.dweight_parts(dy, x, S, block_rows=rows).float().sum(0), ref) < 4e-3, (T, S, N, K, rows)
+    # views: column slices of wider activations (leading dimension != width)
+    wide_dy = (torch.randn(2048, 768, device=dev) / 8).to(torch.bfloat16)
+    wide_x = torch.randn(2048, 512, device=dev).to(torch.bfloat16)
+    parts = nv.dweight_parts(wide_dy[:, 256:512], wide_x[:, 128:384], 8)
+    assert rel(parts.float().sum(0), wide_dy[:, 256:512].float().t() @ wide_x[:, 128:384].float()) < 4e-3
+    assert not nv.dweight_ok(wide_dy[:100], wide_x[:100], 1)       # T not a multiple of 64
+    assert not nv.dweight_ok(wide_dy[:, :200], wide_x, 8)          # N not a multiple of 128
+    with pytest.raises(nv.NativeError):
+        nv.dweight_parts(wide_dy, wide_x, 12)
