@@ -204,7 +204,7 @@ def _hip_linear(x2: torch.Tensor, wb: torch.Tensor, bias_f32=None):
     hipBLASLt's pick on this chip (K <= 256 with a wide output: linear1 forward 55 -> 38 us, linear2 input gradient
     48 -> 38 us at 34 816 tokens; tools/probe_linear.py), else None."""
     K, N = x2.shape[-1], wb.shape[0]
-    if K > 256 or N < 512 or N % 256 or x2.shape[0] < 4096:
+    if K > 256 or N % 256 or x2.shape[0] < 4096:
         return None
     from ..g2048 import native as nv
 
@@ -291,7 +291,7 @@ def _dweight(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     42 us, 4x faster, and the f32 sum is at least as accurate as the single bf16-output GEMM it replaces."""
     T, S = x2.shape[0], _LinearSplitK.SLICES
     if T % S == 0 and T // S >= 1024:
-        return _sum_f32(torch.bmm(dy2.view(S, T // S, -1).transpose(1, 2), x2.view(S, T // S, -1)))
+        return _sum_f32(_dweight_parts(dy2, x2))  # g2048_dweight_bf16 when it takes the operands, else the batched GEMM
     return (dy2.t() @ x2).float()
 
 
@@ -643,7 +643,8 @@ class _LinearAddLayerNorm(torch.autograd.Function):
 
         ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None, not as a zero-filled tensor
         with torch.autocast("cuda", enabled=False):
-            a = F.linear(u, wb, bb)  # (out_proj 256 -> 256 through g2048_linear_bf16: measured, no difference)
+            a = _hip_linear(u.reshape(-1, u.shape[-1]), wb, bias.detach()) if bias is not None and u.is_contiguous() else None
+            a = F.linear(u, wb, bb) if a is None else a.view(*u.shape[:-1], wb.shape[0])
         ctx.wbT, ctx.link = wbT, link
         ctx.params = (weight, bias, gamma, beta)
         ctx.cls_link = cls_link

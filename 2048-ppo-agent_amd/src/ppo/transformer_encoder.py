@@ -80,7 +80,7 @@ class TransformerEncoder(nn.Module):
         (``Bf16Shadow``), else a list of None (``_linear`` then uses the masters directly)."""
         layers = self.encoder.layers
         if not _train_bf16(like, layers[0].linear1.weight):
-            return [[None] * 9 for _ in layers]
+            return [[None] * 10 for _ in layers]
         if self._shadow is None:
             ps = []
             for l in layers:
@@ -89,13 +89,15 @@ class TransformerEncoder(nn.Module):
             last = len(layers) - 1
             # [in, out] copies: linear2 of every layer (masked input-gradient GEMM); fragment-packed copies (tensor and transpose) of
             # out_proj, linear1 and linear2 of the LAST layer (the fused CLS tail, g2048_cls_tail_fwd / _bwd)
-            self._shadow = Bf16Shadow(ps, transposed=[8 * i + 6 for i in range(len(layers))],
+            # (+ out_proj^T of the layers in front of it: the input gradient of out_proj through g2048_linear_bf16)
+            self._shadow = Bf16Shadow(ps, transposed=[8 * i + 6 for i in range(len(layers))] + [8 * i + 2 for i in range(last)],
                                       packed=[8 * last + 2, 8 * last + 4, 8 * last + 6])
         v = self._shadow()
-        return [v[8 * i:8 * i + 8] + [self._shadow.tviews[8 * i + 6]] for i in range(len(layers))]
+        tv = self._shadow.tviews
+        return [v[8 * i:8 * i + 8] + [tv[8 * i + 6], tv.get(8 * i + 2)] for i in range(len(layers))]
 
     def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor, h: torch.Tensor, next_norm,
-               cls_only: bool = False, sh=(None,) * 9, cls_link_out=None, cls_link_in=None, tail_heads=None):
+               cls_only: bool = False, sh=(None,) * 10, cls_link_out=None, cls_link_in=None, tail_heads=None):
         """One pre-norm encoder layer.  ``h`` = norm1(x), already computed (by the previous layer's tail); returns
         (x_out, next_norm(x_out)) so that every residual add + dropout + LayerNorm is one fused kernel
         (``_add_norm``); ``next_norm`` None: (x_out, None).  With ``cls_only`` only the CLS row of the output is
@@ -144,7 +146,7 @@ class TransformerEncoder(nn.Module):
             # update path: out_proj + add + LayerNorm, linear1 + ReLU + dropout, linear2 + add + LayerNorm as three ops
             n2 = layer.norm2
             x, h = _LinearAddLayerNorm.apply(a, attn.out_proj.weight, attn.out_proj.bias, sh[2], sh[3], x, n2.weight,
-                                             n2.bias, n2.eps, p)
+                                             n2.bias, n2.eps, p, sh[9])
             link = FFNLink(p) if next_norm is not None else None
             f = _LinearReluDropout.apply(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5], p, link)
             if next_norm is None:
