@@ -52,8 +52,8 @@ __host__ __device__ constexpr int dw_nbuf(int bn) { return (160 * 1024) / (TOKS 
 // issues 32 transposed reads, their address arithmetic and 8 x ~10 instructions of fetch bookkeeping.
 template <int NTW, int WN>
 __global__ void __launch_bounds__(128 * WN, 1)
-k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict__ x, int64_t ldx, __bf16 *__restrict__ parts, int64_t T,
-          int N, int K, int slices, int k_blocks) {
+k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict__ x, int64_t ldx, __bf16 *__restrict__ parts,
+          float *__restrict__ colsum, int64_t T, int N, int K, int slices, int k_blocks) {
     constexpr int BN = 32 * NTW * WN, KTW = 2, NW = 2 * WN, THREADS = 64 * NW;
     constexpr int NBUF = dw_nbuf(BN), DIST = NBUF - 1;  // stage buffers; stages in flight ahead of the one being multiplied
     constexpr int ROWA = BN * 2, ROWB = BK * 2;            // LDS row bytes of the two tiles
@@ -99,6 +99,11 @@ k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict_
     for (int t = 0; t < NTW; ++t) colA[t] = laneA + 64u * (uint32_t)((NTW * wn + t) ^ q);
     for (int t = 0; t < KTW; ++t) colB[t] = laneB + 64u * (uint32_t)((KTW * wk + t) ^ q);
 
+    // column sums of dY over the slice's tokens (the Linear's bias gradient) ride along in the workgroups of column block 0: a wave's
+    // A operand already holds 8 tokens of one column per lane
+    const bool do_cs = colsum != nullptr && kb == 0 && wk == 0;
+    float cs[NTW];
+    for (int t = 0; t < NTW; ++t) cs[t] = 0.f;
     f32x16 acc[NTW][KTW];
     for (int a = 0; a < NTW; ++a)
         for (int b = 0; b < KTW; ++b)
@@ -133,6 +138,16 @@ k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict_
         bf16x8 fa[KSTEPS][NTW], fb[KSTEPS][KTW];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) frags(A, B, ks, fa[ks], fb[ks]);
+        if (do_cs) {
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const uint4 u = __builtin_bit_cast(uint4, fa[ks][t]);
+                    cs[t] += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xFFFF0000u)) + (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xFFFF0000u)) +
+                             (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xFFFF0000u)) + (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xFFFF0000u));
+                }
+        }
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
@@ -143,6 +158,13 @@ k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict_
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][a], fb[ks][b], acc[a][b], 0, 0, 0);
                     if (m % DMA_EVERY == DMA_EVERY - 1 && m / DMA_EVERY < PER && more) fetch_one(s + DIST, m / DMA_EVERY);
                 }
+        }
+    }
+    if (colsum != nullptr && kb == 0) {  // (wave-uniform; the shuffle needs every lane of the wave)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const float v = cs[t] + __shfl_xor(cs[t], 32);
+            if (wk == 0 && h == 0) colsum[(int64_t)slice * N + n0 + 32 * (NTW * wn + t) + r] = v;
         }
     }
     // ---- epilogue: the block as bf16 through LDS (rows of 256 bytes), then full rows to parts[slice][n0 ..][k0 ..]
@@ -166,11 +188,11 @@ k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict_
 
 }  // namespace
 
-extern "C" int g2048_dweight_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, void *parts, int64_t T, int N, int K,
-                                  int slices, int block_rows, void *stream) {
+extern "C" int g2048_dweight_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, void *parts, float *colsum, int64_t T, int N,
+                                  int K, int slices, int block_rows, void *stream) {
     if (!dy || !x || !parts || T <= 0 || N < 128 || N % 128 || K < BK || K % BK || slices < 1 || (slices >= 8 && slices % 8) ||
         T % ((int64_t)TOKS * slices) || lddy < N || ldx < K || (lddy & 7) || (ldx & 7) ||
-        (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)parts) & 15) || lddy * 2 * 4 >= (1ll << 31) || ldx * 2 * 4 >= (1ll << 31) ||
+        (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)parts) & 15) || ((uintptr_t)colsum & 3) || lddy * 2 * 4 >= (1ll << 31) || ldx * 2 * 4 >= (1ll << 31) ||
         (block_rows != 0 && block_rows != 128 && block_rows != 256) || (block_rows == 256 && N % 256))
         return G2048_EINVAL;
     const int k_blocks = K / BK;
@@ -183,10 +205,10 @@ extern "C" int g2048_dweight_bf16(const void *dy, int64_t lddy, const void *x, i
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -(1000 + (int)hipGetLastError());
     if (wide)
         hipLaunchKernelGGL((k_dweight<2, 4>), grid, dim3(512), lds, (hipStream_t)stream, (const __bf16 *)dy, lddy, (const __bf16 *)x, ldx,
-                           (__bf16 *)parts, T, N, K, slices, k_blocks);
+                           (__bf16 *)parts, colsum, T, N, K, slices, k_blocks);
     else
         hipLaunchKernelGGL((k_dweight<1, 4>), grid, dim3(512), lds, (hipStream_t)stream, (const __bf16 *)dy, lddy, (const __bf16 *)x, ldx,
-                           (__bf16 *)parts, T, N, K, slices, k_blocks);
+                           (__bf16 *)parts, colsum, T, N, K, slices, k_blocks);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }

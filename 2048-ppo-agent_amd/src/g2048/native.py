@@ -77,7 +77,7 @@ SIGNATURES = {
     "g2048_cls_tail_fwd": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_cls_tail_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_dweight_t": [_vp, _i32, _i64, _i64, _i32, _vp],
-    "g2048_dweight_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
+    "g2048_dweight_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "g2048_opt_workspace_floats": [_i32],
     "g2048_opt_step": [_vp, _i32, _vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _i32, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp, _vp],
 }
@@ -773,16 +773,19 @@ def dweight_ok(dy2: torch.Tensor, x2: torch.Tensor, slices: int) -> bool:
     return N % 128 == 0 and K % 128 == 0 and T > 0 and T % (64 * slices) == 0 and (slices < 8 or slices % 8 == 0)
 
 
-def dweight_parts(dy2: torch.Tensor, x2: torch.Tensor, slices: int, out: torch.Tensor = None, block_rows: int = 0) -> torch.Tensor:
-    """bf16 [slices, N, K] whose sum over the first axis is dY^T X (``g2048_dweight_bf16``)."""
+def dweight_parts(dy2: torch.Tensor, x2: torch.Tensor, slices: int, out: torch.Tensor = None, block_rows: int = 0, colsum: bool = False):
+    """bf16 [slices, N, K] whose sum over the first axis is dY^T X (``g2048_dweight_bf16``); with ``colsum`` also f32 [slices, N] whose
+    sum over the first axis is ``dy2.sum(0)``: -> (parts, column sums)."""
     if not dweight_ok(dy2, x2, slices):
         raise NativeError(f"dweight_parts: operands {tuple(dy2.shape)} x {tuple(x2.shape)} with {slices} slices are not supported")
     T, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
     if out is None:
         out = torch.empty((slices, N, K), dtype=torch.bfloat16, device=dy2.device)
+    cs = torch.empty((slices, N), dtype=f32, device=dy2.device) if colsum else None
     _check(load().g2048_dweight_bf16(dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0), _dev(out, torch.bfloat16, slices * N * K, "parts"),
-                                     T, N, K, int(slices), int(block_rows), _stream()), "g2048_dweight_bf16")
-    return out
+                                     None if cs is None else cs.data_ptr(), T, N, K, int(slices), int(block_rows), _stream()),
+           "g2048_dweight_bf16")
+    return (out, cs) if colsum else out
 
 
 def dweight_t(jobs, ld: int, m: int, slices: int):

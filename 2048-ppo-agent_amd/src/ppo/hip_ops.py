@@ -260,6 +260,24 @@ def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     return (dy2.t() @ x2).unsqueeze(0)
 
 
+def _sink_weight_bias(sink, weight, bias, dy2, x2, w_offset: int = 0, b_offset: int = 0):
+    """Weight and bias gradient of one Linear into the sink; for a minibatch-sized token axis ONE launch produces the first stage of
+    both (``g2048_dweight_bf16`` with column sums)."""
+    if bias is not None and x2.shape[0] >= 16384:
+        from ..g2048 import native as nv
+
+        N, K = dy2.shape[1], x2.shape[1]
+        slices = 16 if N * K > 256 * 256 else 32
+        if nv.dweight_ok(dy2, x2, slices):
+            parts, cs = nv.dweight_parts(dy2, x2, slices, block_rows=128, colsum=True)
+            sink.add(weight, parts, N * K, N * K, slices, w_offset)
+            sink.add(bias, cs, N, N, slices, b_offset)
+            return
+    _sink_weight(sink, weight, dy2, x2, w_offset)
+    if bias is not None:
+        _sink_bias(sink, bias, dy2, b_offset)
+
+
 def _sink_weight(sink, param, dy2, x2, dst_offset: int = 0):
     parts = _dweight_parts(dy2, x2)
     n = parts.shape[1] * parts.shape[2]
@@ -333,9 +351,7 @@ class _LinearSplitK(torch.autograd.Function):
             weight, bias = ctx.params
             sink = _sink_for(weight, bias) if w_dtype == torch.float32 and b_dtype in (None, torch.float32) else None
             if sink is not None:
-                _sink_weight(sink, weight, dy2, x2)
-                if bias is not None:
-                    _sink_bias(sink, bias, dy2)
+                _sink_weight_bias(sink, weight, bias, dy2, x2)
                 return dx, None, None, None, None
             dw = _dweight(dy2, x2).to(w_dtype)
             db = None if b_dtype is None else _colsum(dy2).to(b_dtype)
@@ -419,9 +435,8 @@ class _InProjCls(torch.autograd.Function):
         sink = _sink_for(weight, bias)
         if sink is not None:  # the four pieces land in their slices of the in_proj gradients
             _sink_weight(sink, weight, dq2, h_cls, 0)
-            _sink_weight(sink, weight, dkv2, h.view(B * S, D), D * D)
             _sink_bias(sink, bias, dq2, 0)
-            _sink_bias(sink, bias, dkv2, D)
+            _sink_weight_bias(sink, weight, bias, dkv2, h.view(B * S, D), D * D, D)
             return dh, None, None, None, None
 
         def weight_grads():

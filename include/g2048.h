@@ -282,9 +282,11 @@ int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias
  * left to g2048_reduce_jobs.  dy bf16 [T][N] and x bf16 [T][K] with leading dimensions lddy / ldx (elements, multiples of 8),
  * parts bf16 [slices][N][K] contiguous; N and K multiples of 128, T a multiple of 64 * slices, slices 1..7 or a multiple of
  * 8; base pointers 16-byte aligned.  f32 accumulation over a slice, one rounding to bf16 per partial.  block_rows: rows of the
- * gradient per workgroup (x 128 columns), 128 or 256 (N a multiple of 256), 0 = the kernel's choice; slices x blocks workgroups. */
-int g2048_dweight_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, void *parts, int64_t T, int N, int K,
-                       int slices, int block_rows, void *stream);
+ * gradient per workgroup (x 128 columns), 128 or 256 (N a multiple of 256), 0 = the kernel's choice; slices x blocks workgroups.
+ * colsum (optional): f32 [slices][N], colsum[s][n] = sum over the slice's tokens of dy[t][n] (f32 sum of the bf16 values) - the
+ * first stage of the Linear's bias gradient `dy.sum(0)`, read off the operand tiles the product stages anyway. */
+int g2048_dweight_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, void *parts, float *colsum, int64_t T, int N,
+                       int K, int slices, int block_rows, void *stream);
 
 /* ---- policy network (update): Linear for tall-skinny activations ------------------------------------------ */
 

@@ -1039,6 +1039,10 @@ def test_dweight_parts_match_f32_reference(dev):
             rows = slice(s * (T // S), (s + 1) * (T // S))
             assert rel(parts[s], dy[rows].float().t() @ x[rows].float()) < 4e-3
             assert torch.equal(parts, nv.dweight_parts(dy, x, S))  # fixed summation order
+            parts2, cs = nv.dweight_parts(dy, x, S, colsum=True)  # the bias gradient's first stage rides along
+            assert torch.equal(parts2, parts) and cs.shape == (S, N) and cs.dtype == torch.float32
+            assert torch.allclose(cs.sum(0), dy.float().sum(0), rtol=1e-4, atol=1e-4 * float(dy.float().abs().sum(0).max()) + 1e-6)
+            assert torch.allclose(cs[s], dy[rows].float().sum(0), rtol=1e-4, atol=1e-4 * float(dy[rows].float().abs().sum(0).max()) + 1e-6)
             if N % 256 == 0 and T <= 1024:  # both block shapes
                 for rows in (128, 256):
                     assert rel(nv.dweight_parts(dy, x, S, block_rows=rows).float().sum(0), ref) < 4e-3, (T, S, N, K, rows)
