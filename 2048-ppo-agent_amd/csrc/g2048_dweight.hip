@@ -134,7 +134,8 @@ k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict_
         // and CU (half of ds_read_b128), and a wave tile of a x b MFMA tiles needs 2 (a + b) / (a b) of them per MFMA - 3 for the
         // 32 x 64 tile of the [128 x 128] block, 2 for the 64 x 64 tile of the [256 x 128] block (measured with the fetches switched
         // off: 22-23 us per [1024 x 256] gradient either way, 0.65 us per 64-token stage; reads one or two k-steps ahead of their
-        // MFMAs instead: the same or slower)
+        // MFMAs instead: the same or slower; two groups of four waves that split a stage's k-steps over the whole block with 64 x 64
+        // tiles, partial blocks added through LDS in the epilogue: 31.4 vs 29.6 us, 344 vs 314 us per minibatch)
         bf16x8 fa[KSTEPS][NTW], fb[KSTEPS][KTW];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) frags(A, B, ks, fa[ks], fb[ks]);
