@@ -18,9 +18,10 @@
 namespace {
 
 constexpr int D = 256, WAVES = 4;
-// rows per workgroup of the add+LN backward: 64 for the 34 816-token activations; 8 for the 2048-row ones of the CLS-only layer
-// (32 workgroups whose waves walk 16 rows each, two dependent wave reductions per row, took 12-16 us for 2 MB)
-__host__ __device__ inline int ln_rows_per_block(int64_t T) { return T >= 16384 ? 64 : 8; }
+// rows per workgroup of the add+LN backward: 32 for the 34 816-token activations (1 088 workgroups: 26.4 us per launch; 64 rows
+// = 544 workgroups 30.8 us; 16 rows no faster and twice the partial rows for g2048_reduce_jobs); 8 for the 2048-row ones of the
+// CLS-only layer (32 workgroups whose waves walk 16 rows each, two dependent wave reductions per row, took 12-16 us for 2 MB)
+__host__ __device__ inline int ln_rows_per_block(int64_t T) { return T >= 16384 ? 32 : 8; }
 
 __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -212,8 +213,10 @@ extern "C" int g2048_add_ln_fwd(const float *x, int64_t x_row_stride, const void
         (((uintptr_t)a | (uintptr_t)h) & 7))
         return G2048_EINVAL;
     const uint32_t thr = a ? (uint32_t)(p_drop * 16777216.0f) : 0u;
+    // four workgroups per CU whose waves walk ~8 rows each with the next row's loads in flight: 21.6 us per [34 816 x 256] launch
+    // (one row per wave, 8 192 workgroups: 24.6 us)
     const int64_t blocks = (T + WAVES - 1) / WAVES;
-    hipLaunchKernelGGL(k_add_ln_fwd, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(64 * WAVES), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL(k_add_ln_fwd, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(64 * WAVES), 0, (hipStream_t)stream, x,
                        x_row_stride, (const uint16_t *)a, gamma, beta, x_new, (uint16_t *)h, mean, rstd, T, eps,
                        1.0f / (1.0f - p_drop), thr, (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
     return done();

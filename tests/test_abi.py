@@ -73,7 +73,7 @@ def test_invalid_arguments_return_einval_without_touching_a_device():
         assert lib.g2048_reduce_jobs(C.cast(job, C.c_void_p), 1, None) == -1
     assert lib.g2048_opt_step(None, 0, a, a, a, None, 0, 0.5, None, 0, None, None, 2.0, 0.5, 2000, None, None, None) == -1
     assert lib.g2048_opt_workspace_floats(10) >= 12
-    assert lib.g2048_add_ln_bwd_workspace_floats(65) == 9 * 3 * 256 and lib.g2048_add_ln_bwd_workspace_floats(34816) == 544 * 3 * 256
+    assert lib.g2048_add_ln_bwd_workspace_floats(65) == 9 * 3 * 256 and lib.g2048_add_ln_bwd_workspace_floats(34816) == 1088 * 3 * 256
     assert lib.g2048_colsum(a, 1, 6, 4, 6, a, a, None) == -1                                  # N not a multiple of 4
     assert lib.g2048_colsum(a, 1, 512, 4, 1024, a, a, None) == -1                             # row stride < N
     assert lib.g2048_relu_dropout_fwd(a, a, 4, 12, 0.1, 0, None, None) == -1                  # F not a multiple of 8
