@@ -185,13 +185,15 @@ k_linear(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ w
 // per lane and k-step).  A wave-instruction of that kind is 64 separate 16-byte requests (lane = row); rocprofv3 showed the waves
 // stalled at instruction issue for 58 % of their cycles (SQ_WAIT_INST_ANY) at 2.0-2.4 TB/s, and neither the instruction order nor the
 // store pattern moved it.  Here the roles are swapped:
-//   * the four waves split the slice's 128 OUTPUT features (one 32-row weight tile each): a wave's whole weight tile over K <= 256 is
-//     16 fragments = 64 registers, loaded once per workgroup from nn.Linear's row-major layout;
-//   * a 128-token tile of X is copied into LDS by LDS-DMA (`global_load_lds`, whole 512-byte rows: perfectly coalesced, no
-//     registers), 16-byte chunks XOR-swizzled by row so that every B fragment is one conflict-free ds_read_b128; every wave multiplies
-//     its weight tile against all four token blocks;
-//   * the output tile goes back through the same LDS buffer (row-major, swizzled) and leaves as full 256-byte rows.
-// 64 KiB of LDS per workgroup = two workgroups per CU: one's DMA hides behind the other's MFMAs and stores.
+//   * the waves of a workgroup (8, or 4 for widths that are not multiples of 256) split the slice's OUTPUT features, one 32-row weight
+//     tile each: a wave's whole weight tile over K <= 256 is 16 fragments = 64 registers, loaded once per workgroup from nn.Linear's
+//     row-major layout;
+//   * 64-token tiles of X are copied into LDS by LDS-DMA (`global_load_lds`, whole 512-byte rows: perfectly coalesced, no registers),
+//     double buffered, 16-byte chunks XOR-swizzled by row so that every B fragment is one conflict-free ds_read_b128; every wave
+//     multiplies its weight tile against both 32-token blocks;
+//   * the output tile goes through an LDS staging tile of its own (row-major, swizzled) and leaves as full rows of the slice.
+// One workgroup per CU (2 x 32 KiB of X + 32 KiB of staging + bias + mask words); the order of fetch, MFMAs, epilogue, wait and stores
+// inside the tile loop is what the comment in front of k_linear_ws is about.
 // Accumulator tile of wave w, token block b: acc[b][i] = Y^T[n0 + 32 w + rowof(i, h)][token 32 b + r].
 __device__ __forceinline__ int rowof(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
@@ -335,9 +337,9 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const bf16x8 *>(wrow + 16 * ks);
     }
-    // Two X buffers: the fetch of tile i + 1 is issued right after the barrier that publishes tile i.  (Issuing it later, while the
-    // storing waves copy tile i out - with a third buffer to keep the lead - measured SLOWER, 30.3 vs 28.5 us at N = 1024: fetches and
-    // stores go through the same texture addresser, and it is what bounds the kernel; overlapping them only makes both slower.)
+    // Two X buffers: the fetch of tile i + 1 is issued right after the barrier that publishes tile i.  (Issuing it later, during the
+    // copy-out of tile i - with a third buffer to keep the lead - measured SLOWER, 30.3 vs 28.5 us at N = 1024: fetches and stores go
+    // through the same texture addresser.)
     constexpr int NB = 2;
     // LDS: the X buffers, the output staging tile, the slice's bias (it enters through the accumulators' initial value, 4 broadcast
     // reads per tile), mask words
