@@ -228,3 +228,55 @@ def test_colsum_wide_and_capture_guard(dev):
     with pytest.raises(RuntimeError, match="must not be captured"):
         with torch.cuda.graph(g):
             _colsum(odd)
+
+
+def _torch_forward(agent, boards, reduction):
+    """The agent's forward out of plain PyTorch modules only (one-hot Linear, nn.TransformerEncoder, the heads): what autocast makes
+    of the reference's architecture, no kernel of this repository."""
+    import torch.nn.functional as F
+
+    t = agent.transformer
+    x = agent.input_embedding(F.one_hot(boards.long(), 31).float())
+    x = x + t.positional_encoding.flat_table().unsqueeze(0).to(x.dtype)
+    x = torch.cat([t.cls_token.expand(x.shape[0], -1, -1).to(x.dtype), x], dim=1)
+    x = t.encoder(x)
+    feats = x[:, 0] if reduction == "cls" else x[:, 1:].mean(dim=1)  # "mean": over the 16 board tokens
+    return agent.actor(feats), agent.critic(feats)
+
+
+@pytest.mark.parametrize("reduction", ["cls", "mean"])
+def test_update_path_gradients_per_tensor_at_minibatch_size(dev, reduction):
+    """Every parameter gradient of the default-shape agent through the HIP update path (bf16 autocast, dropout 0, minibatch 2048 =
+    34 816 tokens: `k_linear_ws`, `k_dweight` with column sums, attention, add+LayerNorm, the fused CLS tail for "cls" / the full last
+    layer for "mean") - per TENSOR, relative to the tensor's own gradient norm, against an fp32 PyTorch backward of the same weights,
+    with PyTorch's own bf16 autocast backward as the yardstick (ReLU units whose pre-activation changes sign under bf16 rounding put
+    ~5 % on every tensor whichever bf16 implementation runs).  Random downstream gradients on logits and values, so nothing cancels
+    (unlike the PPO loss of the bench-shape test)."""
+    agent = default_shape_agent(dropout=0.0).to(dev)
+    agent.reduction = reduction
+    agent.train()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    boards = torch.randint(0, 12, (2048, 16), generator=g, dtype=torch.uint8).to(dev)
+    gl, gv = torch.randn(2048, 4, generator=g).to(dev), torch.randn(2048, generator=g).to(dev)
+
+    def grads(model, fwd, autocast):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            lo, va = fwd(model)
+        ((lo.float() * gl).sum() + (va.float().flatten() * gv).sum()).backward()
+        return [p.grad.detach().float().clone() for p in model.parameters()], lo.detach().float(), va.detach().float().flatten()
+
+    ref = copy.deepcopy(agent).float()
+    ref.transformer._shadow, ref._head_shadow = None, None
+    g32, l32, v32 = grads(ref, lambda m: _torch_forward(m, boards, reduction), False)
+    g16, _, _ = grads(ref, lambda m: _torch_forward(m, boards, reduction), True)
+    gh, lh, vh = grads(agent, lambda m: m(boards, None), True)
+    assert (lh - l32).abs().max().item() < 0.05 and (vh - v32).abs().max().item() < 0.05
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+    bad = {}
+    for (n, _), a32, a16, ah in zip(agent.named_parameters(), g32, g16, gh):
+        assert torch.isfinite(ah).all(), n
+        e_hip, e_torch = rel(ah, a32), rel(a16, a32)
+        if not e_hip < 1.3 * e_torch + 0.01:
+            bad[n] = (round(e_hip, 4), round(e_torch, 4))
+    assert not bad, (reduction, bad)
