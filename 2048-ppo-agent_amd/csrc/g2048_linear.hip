@@ -312,8 +312,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //     other's epilogue: 39.8 us - the 64-byte row segments a single wave can store are half cache lines.
 // What is left (stamps): of ~5 000 cycles per tile the MFMA phase takes 2 170 for 1 024 cycles of MFMA per wave - both waves of a SIMD
 // are in it at the same time and the matrix pipe idles through the other phases (epilogue 630, copy-out 750, fetch issue 450,
-// barriers ~900).  Running token block 0's epilogue in the shadow of block 1's MFMAs was tried with sched_group_barrier masks: the
-// solver dropped the whole pipeline (ds_read -> wait -> MFMA, no prefetch); it would take the hand-cut steps of the rollout encoder.
+// barriers ~900).  Token block 0's epilogue runs in the shadow of block 1's MFMAs (hand-cut steps with sched_barrier fences as in the
+// rollout encoder; with sched_group_barrier masks the solver dropped the whole pipeline): 120.9 -> 111.6 us per minibatch for the
+// ReLU + dropout variant, 103.5 -> 101.9 for the masked backward, +-0 for the plain one (same box).  Hashing block 1's keep bits during
+// block 0's MFMAs as well: no further gain.
 // Two independent workgroups per CU would interleave the phases, but need <= 128 registers per wave; the weight tile alone is 64.
 // WAVES = 8: a 256-wide slice of N per workgroup - the X tile goes through the CU's vector-memory path once per 256 outputs instead of
 // once per 128 (30.9 -> 28.9 us); WAVES = 4: 128-wide, for widths that are not multiples of 256.  One workgroup per CU either way.
@@ -395,72 +397,95 @@ k_linear_ws(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict_
                 acc[b][4 * g + 0] = bv.x; acc[b][4 * g + 1] = bv.y; acc[b][4 * g + 2] = bv.z; acc[b][4 * g + 3] = bv.w;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(xb + (32 * b + r) * row_bytes + (((2 * ks + h) ^ (r & 15)) * 16));
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], bf, acc[b], 0, 0, 0);
-            }
-        }
-        // issue order: B fragments PRE reads ahead of their MFMAs (left alone the compiler keeps two reads in flight, and every MFMA
-        // then waits out an LDS round trip that 8 waves per CU make long)
-        {
-            constexpr int PRE = 8, N = 2 * KS;
-            __builtin_amdgcn_sched_group_barrier(0x100, PRE, 0);
-#pragma unroll
-            for (int i = 0; i < N - PRE; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, PRE, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        WS_STAMP(3);
-        // ---- epilogue: lane = token 32 b + r, registers 4g..4g+3 = output features n0 + 32 w + 8g + 4h .. +3
+        // ---- epilogue pieces.  Lane = token 32 b + r, registers 4g..4g+3 = output features n0 + 32 w + 8g + 4h .. +3.
         const int nw = n0 + 32 * w;
         uint32_t obits = 0u;  // bit 16 b + i: output (b, i) of this lane is non-zero after rounding
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int64_t tok = tok0 + 32 * b + r;
-            const bool valid = tok < T;
-            if (EPI == EPI_RELU_DROPOUT) {
-                // one 32-bit hash per pair of neighbouring columns, 16 bits each (index = element index / 2, the seed's high
-                // word through E.hi_term: the convention of the round-2 kernel)
-                const uint32_t pair0 = (uint32_t)(((uint64_t)(valid ? tok : T - 1) * (uint64_t)E.row_elems + (uint64_t)(nw + 4 * h)) >> 1);
-                for (int i = 0; i < 16; i += 2) {
-                    float a = fmaxf(acc[b][i], 0.f), c = fmaxf(acc[b][i + 1], 0.f);
-                    if (E.thr16) {
-                        uint32_t xh = (pair0 + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2))) * 0x9E3779B1u + E.hi_term;
-                        xh ^= xh >> 16; xh *= 0x7FEB352Du; xh ^= xh >> 15; xh *= 0x846CA68Bu; xh ^= xh >> 16;
-                        a = (xh & 0xFFFFu) >= E.thr16 ? a * E.inv_keep : 0.f;
-                        c = (xh >> 16) >= E.thr16 ? c * E.inv_keep : 0.f;
-                    }
-                    acc[b][i] = a; acc[b][i + 1] = c;
-                }
-            }
+        // ReLU + dropout of the pair of columns (i, i + 1), i = 2 pi: one 32-bit hash per pair, 16 bits each (index = element index / 2,
+        // the seed's high word through E.hi_term: the convention of the round-2 kernel); p = 0: thr16 = 0 keeps everything
+        auto keep_pair = [&](int pi, uint32_t pair0) -> uint32_t {  // bit 0 / 1: column i / i + 1 is kept
+            const int i = 2 * pi;
+            uint32_t xh = (pair0 + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2))) * 0x9E3779B1u + E.hi_term;
+            xh ^= xh >> 16; xh *= 0x7FEB352Du; xh ^= xh >> 15; xh *= 0x846CA68Bu; xh ^= xh >> 16;
+            return ((xh & 0xFFFFu) >= E.thr16 ? 1u : 0u) | ((xh >> 16) >= E.thr16 ? 2u : 0u);
+        };
+        auto drop_pair = [&](int b, int pi, uint32_t keep) {
+            const int i = 2 * pi;
+            const float a = fmaxf(acc[b][i], 0.f), c = fmaxf(acc[b][i + 1], 0.f);
+            acc[b][i] = (keep & 1u) ? a * E.inv_keep : 0.f;
+            acc[b][i + 1] = (keep & 2u) ? c * E.inv_keep : 0.f;
+        };
+        // the four outputs of group g: forward's mask (masked backward), rounding, non-zero bits, column sums, staging tile
+        auto finish_g = [&](int b, int g, bool valid) {
             if (EPI == EPI_MASK_COLSUM) {
-                const uint32_t wbits = bits_in >> (16 * b);
-                for (int i = 0; i < 16; ++i) acc[b][i] = ((wbits >> i) & 1u) ? acc[b][i] * E.inv_keep : 0.f;
+                const uint32_t wbits = bits_in >> (16 * b + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[b][4 * g + j] = ((wbits >> j) & 1u) ? acc[b][4 * g + j] * E.inv_keep : 0.f;
             }
-            for (int g = 0; g < 4; ++g) {
-                const uint32_t lo = pack2(acc[b][4 * g + 0], acc[b][4 * g + 1]), hi = pack2(acc[b][4 * g + 2], acc[b][4 * g + 3]);
-                if (EPI == EPI_RELU_DROPOUT) {
-                    const uint32_t nz = ((lo & 0x7FFFu) ? 1u : 0u) | ((lo & 0x7FFF0000u) ? 2u : 0u) | ((hi & 0x7FFFu) ? 4u : 0u) |
-                                        ((hi & 0x7FFF0000u) ? 8u : 0u);
-                    obits |= nz << (16 * b + 4 * g);
-                }
-                if (EPI == EPI_MASK_COLSUM && valid) {  // what at::sum over the bf16 tensor would add
-                    colacc[4 * g + 0] += __uint_as_float(lo << 16);
-                    colacc[4 * g + 1] += __uint_as_float(lo & 0xFFFF0000u);
-                    colacc[4 * g + 2] += __uint_as_float(hi << 16);
-                    colacc[4 * g + 3] += __uint_as_float(hi & 0xFFFF0000u);
-                }
-                // staging tile: rows of 2 NSW bytes, 16-byte chunk c of row q at c ^ (q & (CPR_Y - 1)); this piece = half a chunk
-                const int trow = 32 * b + r, c = 4 * w + g;
-                *reinterpret_cast<uint2 *>(stage + trow * (2 * NSW) + ((c ^ (trow & (CPR_Y - 1))) * 16) + 8 * h) = make_uint2(lo, hi);
+            const uint32_t lo = pack2(acc[b][4 * g + 0], acc[b][4 * g + 1]), hi = pack2(acc[b][4 * g + 2], acc[b][4 * g + 3]);
+            if (EPI == EPI_RELU_DROPOUT) {
+                const uint32_t nz = ((lo & 0x7FFFu) ? 1u : 0u) | ((lo & 0x7FFF0000u) ? 2u : 0u) | ((hi & 0x7FFFu) ? 4u : 0u) |
+                                    ((hi & 0x7FFF0000u) ? 8u : 0u);
+                obits |= nz << (16 * b + 4 * g);
             }
+            if (EPI == EPI_MASK_COLSUM) {  // what at::sum over the bf16 tensor would add (rows past T add nothing)
+                colacc[4 * g + 0] += valid ? __uint_as_float(lo << 16) : 0.f;
+                colacc[4 * g + 1] += valid ? __uint_as_float(lo & 0xFFFF0000u) : 0.f;
+                colacc[4 * g + 2] += valid ? __uint_as_float(hi << 16) : 0.f;
+                colacc[4 * g + 3] += valid ? __uint_as_float(hi & 0xFFFF0000u) : 0.f;
+            }
+            // staging tile: rows of 2 NSW bytes, 16-byte chunk c of row q at c ^ (q & (CPR_Y - 1)); this piece = half a chunk
+            const int trow = 32 * b + r, c = 4 * w + g;
+            *reinterpret_cast<uint2 *>(stage + trow * (2 * NSW) + ((c ^ (trow & (CPR_Y - 1))) * 16) + 8 * h) = make_uint2(lo, hi);
+        };
+        const bool valid0 = tok0 + r < T, valid1 = tok0 + 32 + r < T;
+        uint32_t pair0[2];
+        for (int b = 0; b < 2; ++b)
+            pair0[b] = (uint32_t)(((uint64_t)((b ? valid1 : valid0) ? tok0 + 32 * b + r : T - 1) * (uint64_t)E.row_elems + (uint64_t)(nw + 4 * h)) >> 1);
+        // ---- 2 KS steps of one MFMA each, in program order (sched_barrier between them: left alone the compiler issues the MFMAs back to
+        // back and the vector work after them).  A step = the MFMA, the B fragment PRE steps ahead, and - during token block 1 - a slice
+        // of token block 0's epilogue, which then runs in the shadow of the matrix pipe (both waves of a SIMD are in this phase together
+        // and keep the pipe saturated; the vector ALU is idle otherwise).
+        {
+            constexpr int PRE = 8, N = 2 * KS;  // step s: block s / KS, k-step s % KS
+            bf16x8 q[PRE];
+            auto frag = [&](int s) {
+                const int b = s / KS, ks = s % KS;
+                return *reinterpret_cast<const bf16x8 *>(xb + (32 * b + r) * row_bytes + (((2 * ks + h) ^ (r & 15)) * 16));
+            };
+#pragma unroll
+            for (int s = 0; s < PRE; ++s) q[s] = frag(s);
+#pragma unroll
+            for (int s = 0; s < N; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int b = s / KS, ks = s % KS;
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], q[s % PRE], acc[b], 0, 0, 0);
+                if (s + PRE < N) q[s % PRE] = frag(s + PRE);
+                constexpr int SPG = KS / 4;  // steps per output group
+                const int g = ks / SPG, t = ks % SPG;
+                if (b == 1) {  // slice ks of block 0's epilogue (KS = 16: pairs at steps 4g and 4g + 2, the group's outputs at 4g + 3)
+                    if (EPI == EPI_RELU_DROPOUT) {
+                        if (SPG >= 4) {
+                            if (t == 0) drop_pair(0, 2 * g, keep_pair(2 * g, pair0[0]));
+                            if (t == 2) drop_pair(0, 2 * g + 1, keep_pair(2 * g + 1, pair0[0]));
+                        } else if (t == 0) {
+                            drop_pair(0, 2 * g, keep_pair(2 * g, pair0[0]));
+                            drop_pair(0, 2 * g + 1, keep_pair(2 * g + 1, pair0[0]));
+                        }
+                    }
+                    if (t == SPG - 1) finish_g(0, g, valid0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        WS_STAMP(3);
+        // ---- token block 1's epilogue
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (EPI == EPI_RELU_DROPOUT) {
+                drop_pair(1, 2 * g, keep_pair(2 * g, pair0[1]));
+                drop_pair(1, 2 * g + 1, keep_pair(2 * g + 1, pair0[1]));
+            }
+            finish_g(1, g, valid1);
         }
         if (EPI == EPI_RELU_DROPOUT && E.bits) bits_ptr(tile)[tid] = obits;
         WS_STAMP(5);
