@@ -106,6 +106,11 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
     const Drop drop = make_drop(seed, seed_state, p_drop);
     float *const xm = reinterpret_cast<float *>(L.xc);
     uint16_t *const masks_wg = reinterpret_cast<uint16_t *>(S.masks) + (int64_t)blockIdx.x * N_MASK_TILES * 64;
+    // gridDim.y == 2: two workgroups per 32 boards, one per head.  Both walk the shared part (out_proj .. features: 1.2 MB of weights),
+    // workgroup 0 saves what the backward needs of it and runs the actor, workgroup 1 runs the critic (0.8 MB each): 2.0 instead of
+    // 2.8 MB through one CU's memory path, which is what the kernel's time is made of (73 -> 52 us).  gridDim.y == 1: both heads here.
+    const int role = gridDim.y == 2 ? (int)blockIdx.y : -1;
+    const bool save = role <= 0;
 
     Ring R;
     auto issue = [&](auto ic) __attribute__((always_inline)) {
@@ -118,9 +123,11 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
                 constexpr int c = (i - 2) / 2;
                 if constexpr ((i - 2) % 2 == 0) fetch_unit<slot>(R, unit_ptr(W.w1, D, 32 * (4 * c + w), 0, lane), NEXT_8_STEPS);
                 else fetch_unit<slot>(R, unit_ptr(W.w2, FF, 32 * (2 * w), FC * c, lane), next_row_tile(FF));
-            } else {
+            } else if (!(role == 0 && i >= 30)) {  // (units 30.. are the critic's: the other workgroup's when the heads are split)
                 constexpr int j = (i - 18) % 12;
-                const void *l1 = i < 30 ? W.a1 : W.c1, *l2 = i < 30 ? W.a2 : W.c2;
+                // the critic's workgroup walks the critic's units right behind the shared part: unit 18 + j of its list = unit 30 + j
+                const bool critic = i >= 30 || role == 1;
+                const void *l1 = critic ? W.c1 : W.a1, *l2 = critic ? W.c2 : W.a2;
                 if constexpr (j < 4) fetch_unit<slot>(R, unit_ptr(l1, D, 32 * (4 * w + j), 0, lane), NEXT_8_STEPS);
                 else fetch_unit<slot>(R, unit_ptr(l2, HID, 32 * (4 * w + (j - 4) / 2), 256 * ((j - 4) % 2), lane), NEXT_8_STEPS);
             }
@@ -183,7 +190,7 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
         for (int p = 0; p < 8; ++p) *reinterpret_cast<float4 *>(xm + (4 * p + (tid >> 6)) * XM_S + 4 * (tid & 63)) = in_x[p];
     }
     lds_barrier();
-    lds_to_T<D>(L.xa, S256, (__bf16 *)S.oT, 0, steps_ld, step_m0, tid);
+    if (save) lds_to_T<D>(L.xa, S256, (__bf16 *)S.oT, 0, steps_ld, step_m0, tid);
 
     // ---- out_proj, dropout, residual add: x_mid = x + dropout(bf16(Wo o + bo))
     {
@@ -220,7 +227,7 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
             float hv[4] = {dx * rstd * gm.x + bt.x, dy * rstd * gm.y + bt.y, dz * rstd * gm.z + bt.z, dw * rstd * gm.w + bt.w};
             if (!ok) hv[0] = hv[1] = hv[2] = hv[3] = 0.f;
             put4(L.xb, S256, row, 4 * lane, hv);
-            if (ok) {
+            if (ok && save) {
                 reinterpret_cast<float4 *>(S.x_mid + (m0 + row) * D)[lane] = v;
                 if (lane == 0) {
                     S.mean[m0 + row] = mean;
@@ -230,7 +237,7 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
         }
     }
     lds_barrier();
-    lds_to_T<D>(L.xb, S256, (__bf16 *)S.h2T, 0, steps_ld, step_m0, tid);
+    if (save) lds_to_T<D>(L.xb, S256, (__bf16 *)S.h2T, 0, steps_ld, step_m0, tid);
 
     // ---- feed-forward: u = dropout(relu(W1 h2 + b1)) in chunks of 128 hidden units, f = W2 u + b2 accumulated per chunk
     {
@@ -253,9 +260,9 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
                 for (int q = 0; q < 4; ++q) bits |= (uint32_t)((float)(__bf16)v[q] != 0.f) << (4 * g + q);
                 put4(ub, S128, r, 32 * w + 8 * g + 4 * h, v);
             }
-            masks_wg[(MT_FFN + ht) * 64 + lane] = (uint16_t)bits;
+            if (save) masks_wg[(MT_FFN + ht) * 64 + lane] = (uint16_t)bits;
             lds_barrier();  // chunk c of every wave visible
-            lds_to_T<FC>(ub, S128, (__bf16 *)S.uT, FC * c, steps_ld, step_m0, tid);
+            if (save) lds_to_T<FC>(ub, S128, (__bf16 *)S.uT, FC * c, steps_ld, step_m0, tid);
             bf16x8 uf[8];
             load_frags<8>(ub, S128, 0, uf, r, h);
             issue(std::integral_constant<int, u2 + DIST>{});
@@ -279,7 +286,7 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
         }
     }
     lds_barrier();
-    lds_to_T<D>(L.xa, S256, (__bf16 *)S.featsT, 0, steps_ld, step_m0, tid);
+    if (save) lds_to_T<D>(L.xa, S256, (__bf16 *)S.featsT, 0, steps_ld, step_m0, tid);
     lds_barrier();  // xc (the f32 residual tile) is dead from here on: the heads write bf16 rows into it
 
     // ---- heads: Linear(256 -> 512) + ReLU, Linear(512 -> 512) + ReLU, Linear(512 -> n_out, no bias) on the features in xa
@@ -354,10 +361,12 @@ k_tail_fwd(const __bf16 *__restrict__ o, const float *__restrict__ x_cls, int64_
         }
         lds_barrier();  // xb / xc are free again
     };
-    head(std::integral_constant<int, 18>{}, std::integral_constant<int, 4>{}, L.bias + BO_AB1, L.bias + BO_AB2, L.w3, MT_A1, MT_A2,
-         (__bf16 *)S.a1T, (__bf16 *)S.a2T, logits);
-    head(std::integral_constant<int, 30>{}, std::integral_constant<int, 1>{}, L.bias + BO_CB1, L.bias + BO_CB2, L.w3 + 4 * HID, MT_C1, MT_C2,
-         (__bf16 *)S.c1T, (__bf16 *)S.c2T, values);
+    if (role != 1)
+        head(std::integral_constant<int, 18>{}, std::integral_constant<int, 4>{}, L.bias + BO_AB1, L.bias + BO_AB2, L.w3, MT_A1, MT_A2,
+             (__bf16 *)S.a1T, (__bf16 *)S.a2T, logits);
+    if (role != 0)
+        head(std::integral_constant<int, 30>{}, std::integral_constant<int, 1>{}, L.bias + BO_CB1, L.bias + BO_CB2, L.w3 + 4 * HID, MT_C1, MT_C2,
+             (__bf16 *)S.c1T, (__bf16 *)S.c2T, values);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -748,7 +757,7 @@ extern "C" int g2048_cls_tail_fwd(const void *o, const float *x_cls, int64_t x_r
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sizeof(TailLds)) != hipSuccess)
         return -(1000 + (int)hipGetLastError());
-    hipLaunchKernelGGL(k_tail_fwd, dim3((unsigned)blocks), dim3(THREADS), sizeof(TailLds), (hipStream_t)stream, (const __bf16 *)o, x_cls,
+    hipLaunchKernelGGL(k_tail_fwd, dim3((unsigned)blocks, 2), dim3(THREADS), sizeof(TailLds), (hipStream_t)stream, (const __bf16 *)o, x_cls,
                        x_row_stride, *W, *S, logits, values, M, eps, p_drop, seed, seed_state);
     return done();
 }
