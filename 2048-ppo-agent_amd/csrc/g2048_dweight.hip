@@ -51,9 +51,9 @@ __host__ __device__ constexpr int dw_nbuf(int bn) { return (160 * 1024) / (TOKS 
 // than the tile shape: one wave alone issues an instruction every ~5 cycles, and per 16 MFMAs (512 cycles of the matrix pipe) a wave also
 // issues 32 transposed reads, their address arithmetic and 8 x ~10 instructions of fetch bookkeeping.
 template <int NTW, int WN>
-__global__ void __launch_bounds__(128 * WN, 1)
-k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict__ x, int64_t ldx, __bf16 *__restrict__ parts,
-          float *__restrict__ colsum, int64_t T, int N, int K, int slices, int k_blocks) {
+__device__ __forceinline__ void dweight_block(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict__ x, int64_t ldx,
+                                              __bf16 *__restrict__ parts, float *__restrict__ colsum, int64_t T, int N, int K, int slices,
+                                              int k_blocks, int block_id) {
     constexpr int BN = 32 * NTW * WN, KTW = 2, NW = 2 * WN, THREADS = 64 * NW;
     constexpr int NBUF = dw_nbuf(BN), DIST = NBUF - 1;  // stage buffers; stages in flight ahead of the one being multiplied
     constexpr int ROWA = BN * 2, ROWB = BK * 2;            // LDS row bytes of the two tiles
@@ -64,8 +64,9 @@ k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wn = w >> 1, wk = w & 1;
-    // workgroup -> (slice, block): the blocks of one token slice have consecutive ids modulo `slices`, a multiple of 8, so they share an XCD
-    const int slice = blockIdx.x % slices, blk = blockIdx.x / slices, nb = blk / k_blocks, kb = blk % k_blocks;
+    // workgroup -> (slice, block): the blocks of one token slice have equal ids modulo `slices`, a multiple of 8, so they share an XCD
+    // (block_id = blockIdx.x minus the job's first workgroup, itself a multiple of 8)
+    const int slice = block_id % slices, blk = block_id / slices, nb = blk / k_blocks, kb = blk % k_blocks;
     const int n0 = nb * BN, k0 = kb * BK;
     const int64_t per_slice = T / slices, tok_first = (int64_t)slice * per_slice;
     const int n_stages = (int)(per_slice / TOKS);
@@ -187,6 +188,29 @@ k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict_
     }
 }
 
+template <int NTW, int WN>
+__global__ void __launch_bounds__(128 * WN, 1)
+k_dweight(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict__ x, int64_t ldx, __bf16 *__restrict__ parts,
+          float *__restrict__ colsum, int64_t T, int N, int K, int slices, int k_blocks) {
+    dweight_block<NTW, WN>(dy, lddy, x, ldx, parts, colsum, T, N, K, slices, k_blocks, (int)blockIdx.x);
+}
+
+// several products in one launch ([128 x 128] blocks): the weight gradients of a whole backward pass, deferred to its end by the caller
+// (GradSink) - no ramp-up and drain per product, and the small ones (a [256 x 256] gradient is 128 workgroups) share the chip
+struct DwJobs {
+    g2048_dwg_job job[G2048_DWG_MAX_JOBS];
+    int32_t first_block[G2048_DWG_MAX_JOBS + 1];
+    int32_t n_jobs;
+};
+__global__ void __launch_bounds__(512, 1)
+k_dweight_jobs(DwJobs J) {
+    int j = 0;
+    while (j + 1 < J.n_jobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;  // <= 16 entries, uniform
+    const g2048_dwg_job &Q = J.job[j];
+    dweight_block<1, 4>((const __bf16 *)Q.dy, Q.lddy, (const __bf16 *)Q.x, Q.ldx, (__bf16 *)Q.parts, Q.colsum, Q.T, Q.N, Q.K, Q.slices, Q.K / BK,
+                        (int)blockIdx.x - J.first_block[j]);
+}
+
 }  // namespace
 
 extern "C" int g2048_dweight_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, void *parts, float *colsum, int64_t T, int N,
@@ -210,6 +234,37 @@ extern "C" int g2048_dweight_bf16(const void *dy, int64_t lddy, const void *x, i
     else
         hipLaunchKernelGGL((k_dweight<1, 4>), grid, dim3(512), lds, (hipStream_t)stream, (const __bf16 *)dy, lddy, (const __bf16 *)x, ldx,
                            (__bf16 *)parts, colsum, T, N, K, slices, k_blocks);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(1000 + (int)e);
+}
+
+static bool dwg_ok(const void *dy, int64_t lddy, const void *x, int64_t ldx, const void *parts, const float *colsum, int64_t T, int N, int K,
+                   int slices) {
+    return dy && x && parts && T > 0 && N >= 128 && N % 128 == 0 && K >= BK && K % BK == 0 && slices >= 1 && !(slices >= 8 && slices % 8) &&
+           T % ((int64_t)TOKS * slices) == 0 && lddy >= N && ldx >= K && !(lddy & 7) && !(ldx & 7) &&
+           !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)parts) & 15) && !((uintptr_t)colsum & 3) && lddy * 2 * 4 < (1ll << 31) &&
+           ldx * 2 * 4 < (1ll << 31);
+}
+
+extern "C" int g2048_dweight_jobs(const g2048_dwg_job *jobs, int n_jobs, void *stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > G2048_DWG_MAX_JOBS) return G2048_EINVAL;
+    DwJobs J;
+    J.n_jobs = n_jobs;
+    int64_t blocks = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const g2048_dwg_job &q = jobs[i];
+        // (a first workgroup that is a multiple of 8 keeps a job's token slices on their XCDs)
+        if (!dwg_ok(q.dy, q.lddy, q.x, q.ldx, q.parts, q.colsum, q.T, q.N, q.K, q.slices) || q.slices % 8) return G2048_EINVAL;
+        J.job[i] = q;
+        J.first_block[i] = (int32_t)blocks;
+        blocks += (int64_t)q.slices * (q.N / 128) * (q.K / BK);
+    }
+    J.first_block[n_jobs] = (int32_t)blocks;
+    if (blocks > 65535 * 16) return G2048_EINVAL;
+    const int lds = dw_nbuf(128) * TOKS * (128 + BK) * 2;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_dweight_jobs), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return -(1000 + (int)hipGetLastError());
+    hipLaunchKernelGGL(k_dweight_jobs, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, J);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }

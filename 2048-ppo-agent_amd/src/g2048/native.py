@@ -78,6 +78,7 @@ SIGNATURES = {
     "g2048_cls_tail_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_dweight_t": [_vp, _i32, _i64, _i64, _i32, _vp],
     "g2048_dweight_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
+    "g2048_dweight_jobs": [_vp, _i32, _vp],
     "g2048_opt_workspace_floats": [_i32],
     "g2048_opt_step": [_vp, _i32, _vp, _vp, _vp, _vp, _i32, C.c_float, _vp, _i32, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp, _vp],
 }
@@ -786,6 +787,31 @@ def dweight_parts(dy2: torch.Tensor, x2: torch.Tensor, slices: int, out: torch.T
                                      None if cs is None else cs.data_ptr(), T, N, K, int(slices), int(block_rows), _stream()),
            "g2048_dweight_bf16")
     return (out, cs) if colsum else out
+
+
+class DwgJob(C.Structure):
+    _fields_ = [("dy", _vp), ("x", _vp), ("parts", _vp), ("colsum", _vp), ("lddy", _i64), ("ldx", _i64), ("T", _i64),
+                ("N", _i32), ("K", _i32), ("slices", _i32), ("pad_", _i32)]
+
+
+DWG_MAX_JOBS = 16
+
+
+def dweight_jobs(jobs):
+    """Several ``dweight_parts`` products in one launch per ``DWG_MAX_JOBS`` (``g2048_dweight_jobs``).  jobs: (dy2, x2, parts bf16
+    [slices, N, K], colsum f32 [slices, N] or None); slices (= parts.shape[0]) a multiple of 8."""
+    recs = []
+    for dy2, x2, parts, cs in jobs:
+        slices = parts.shape[0]
+        if not dweight_ok(dy2, x2, slices) or slices % 8:
+            raise NativeError(f"dweight_jobs: operands {tuple(dy2.shape)} x {tuple(x2.shape)} with {slices} slices are not supported")
+        T, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
+        recs.append(DwgJob(dy2.data_ptr(), x2.data_ptr(), _dev(parts, torch.bfloat16, slices * N * K, "parts"),
+                           None if cs is None else _dev(cs, f32, slices * N, "colsum"), dy2.stride(0), x2.stride(0), T, N, K, slices, 0))
+    for i in range(0, len(recs), DWG_MAX_JOBS):
+        chunk = recs[i:i + DWG_MAX_JOBS]
+        arr = (DwgJob * len(chunk))(*chunk)
+        _check(load().g2048_dweight_jobs(C.cast(arr, _vp), len(chunk), _stream()), "g2048_dweight_jobs")
 
 
 def dweight_t(jobs, ld: int, m: int, slices: int):

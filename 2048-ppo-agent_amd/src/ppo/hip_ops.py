@@ -117,6 +117,7 @@ class GradSink:
 
     def __init__(self, targets: dict):
         self.targets, self.jobs, self.written = targets, [], set()
+        self.dw_jobs = []  # minibatch-sized weight gradients deferred to flush(): one grouped launch (g2048_dweight_jobs)
 
     def takes(self, *params) -> bool:
         return all(p is not None and id(p) in self.targets for p in params)
@@ -129,9 +130,23 @@ class GradSink:
         self.jobs.append((src, dst, part_stride, n, parts, transpose_rows))
         self.written.add(id(param))
 
+    def add_dweight(self, weight, bias, dy2: torch.Tensor, x2: torch.Tensor, slices: int, w_offset: int = 0, b_offset: int = 0):
+        """dW = dy2^T x2 (and db = column sums of dy2) computed at ``flush`` together with every other deferred product; the partials
+        are registered for the reduction now.  dy2 / x2 stay alive until then (~0.5 GB at minibatch 2048)."""
+        N, K = dy2.shape[1], x2.shape[1]
+        parts = torch.empty((slices, N, K), dtype=torch.bfloat16, device=dy2.device)
+        cs = torch.empty((slices, N), dtype=torch.float32, device=dy2.device) if bias is not None else None
+        self.dw_jobs.append((dy2, x2, parts, cs))
+        self.add(weight, parts, N * K, N * K, slices, w_offset)
+        if bias is not None:
+            self.add(bias, cs, N, N, slices, b_offset)
+
     def flush(self):
         from ..g2048 import native as nv
 
+        if self.dw_jobs:
+            nv.dweight_jobs(self.dw_jobs)
+            self.dw_jobs = []
         nv.reduce_jobs(self.jobs)
         self.jobs = []
 
@@ -260,25 +275,33 @@ def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     return (dy2.t() @ x2).unsqueeze(0)
 
 
-def _sink_weight_bias(sink, weight, bias, dy2, x2, w_offset: int = 0, b_offset: int = 0):
-    """Weight and bias gradient of one Linear into the sink; for a minibatch-sized token axis ONE launch produces the first stage of
-    both (``g2048_dweight_bf16`` with column sums)."""
-    if bias is not None and x2.shape[0] >= 16384:
-        from ..g2048 import native as nv
+def _deferred_dweight(sink, weight, bias, dy2, x2, w_offset: int = 0, b_offset: int = 0) -> bool:
+    """A minibatch-sized token axis: the product joins the sink's grouped launch.  slices: [128 x 128] blocks x slices = 128-256
+    workgroups per product."""
+    if x2.shape[0] < 16384:
+        return False
+    from ..g2048 import native as nv
 
-        N, K = dy2.shape[1], x2.shape[1]
-        slices = 16 if N * K > 256 * 256 else 32
-        if nv.dweight_ok(dy2, x2, slices):
-            parts, cs = nv.dweight_parts(dy2, x2, slices, block_rows=128, colsum=True)
-            sink.add(weight, parts, N * K, N * K, slices, w_offset)
-            sink.add(bias, cs, N, N, slices, b_offset)
-            return
+    slices = 16 if dy2.shape[1] * x2.shape[1] > 256 * 256 else 32
+    if not nv.dweight_ok(dy2, x2, slices):
+        return False
+    sink.add_dweight(weight, bias, dy2, x2, slices, w_offset, b_offset)
+    return True
+
+
+def _sink_weight_bias(sink, weight, bias, dy2, x2, w_offset: int = 0, b_offset: int = 0):
+    """Weight and bias gradient of one Linear into the sink; for a minibatch-sized token axis ONE (deferred, grouped) launch produces
+    the first stage of both (``g2048_dweight_jobs`` with column sums)."""
+    if bias is not None and _deferred_dweight(sink, weight, bias, dy2, x2, w_offset, b_offset):
+        return
     _sink_weight(sink, weight, dy2, x2, w_offset)
     if bias is not None:
         _sink_bias(sink, bias, dy2, b_offset)
 
 
 def _sink_weight(sink, param, dy2, x2, dst_offset: int = 0):
+    if _deferred_dweight(sink, param, None, dy2, x2, dst_offset):
+        return
     parts = _dweight_parts(dy2, x2)
     n = parts.shape[1] * parts.shape[2]
     sink.add(param, parts, n, n, parts.shape[0], dst_offset)

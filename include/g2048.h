@@ -288,6 +288,17 @@ int g2048_relu_dropout_bwd(const void *dy, const void *y, void *dx, float *dbias
 int g2048_dweight_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx, void *parts, float *colsum, int64_t T, int N,
                        int K, int slices, int block_rows, void *stream);
 
+/* The same for several Linears in ONE launch (the weight gradients of a whole backward pass, deferred to its end by the caller):
+ * job j is g2048_dweight_bf16(dy, lddy, x, ldx, parts, colsum, T, N, K, slices, 128) with slices a multiple of 8.  jobs: host array,
+ * read during the call. */
+#define G2048_DWG_MAX_JOBS 16
+typedef struct {
+    const void *dy; const void *x; void *parts; float *colsum;
+    int64_t lddy, ldx, T;
+    int32_t N, K, slices, pad_;
+} g2048_dwg_job;
+int g2048_dweight_jobs(const g2048_dwg_job *jobs, int n_jobs, void *stream);
+
 /* ---- policy network (update): Linear for tall-skinny activations ------------------------------------------ */
 
 /* y[T][N] = x[T][K] . weight[N][K]^T (+ bias[N]) - nn.Linear in bf16 with f32 accumulation (reference: every nn.Linear

@@ -1046,6 +1046,19 @@ def test_dweight_parts_match_f32_reference(dev):
             if N % 256 == 0 and T <= 1024:  # both block shapes
                 for rows in (128, 256):
                     assert rel(nv.dweight_parts(dy, x, S, block_rows=rows).float().sum(0), ref) < 4e-3, (T, S, N, K, rows)
+    # several products in one launch (what the GradSink does with a backward pass's weight gradients): bit-identical to the single launches
+    jobs = []
+    for T, N, K, S in ((34816, 1024, 256, 16), (34816, 256, 256, 32), (2048, 768, 128, 8), (34816, 256, 1024, 16)):
+        dy = (torch.randn(T, N, device=dev) / 8).to(torch.bfloat16)
+        x = torch.randn(T, K, device=dev).to(torch.bfloat16)
+        jobs.append((dy, x, torch.empty(S, N, K, dtype=torch.bfloat16, device=dev),
+                     torch.empty(S, N, dtype=torch.float32, device=dev) if N != 768 else None))
+    nv.dweight_jobs(jobs)
+    for dy, x, parts, cs in jobs:
+        want = nv.dweight_parts(dy, x, parts.shape[0], block_rows=128, colsum=cs is not None)
+        assert torch.equal(parts, want[0] if cs is not None else want)
+        if cs is not None:
+            assert torch.equal(cs, want[1])
     # views: column slices of wider activations (leading dimension != width)
     wide_dy = (torch.randn(2048, 768, device=dev) / 8).to(torch.bfloat16)
     wide_x = torch.randn(2048, 512, device=dev).to(torch.bfloat16)
