@@ -276,13 +276,14 @@ def _dweight_parts(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
 
 
 def _deferred_dweight(sink, weight, bias, dy2, x2, w_offset: int = 0, b_offset: int = 0) -> bool:
-    """A minibatch-sized token axis: the product joins the sink's grouped launch.  slices: [128 x 128] blocks x slices = 128-256
-    workgroups per product."""
+    """A minibatch-sized token axis: the product joins the sink's grouped launch.  8 token slices (one per XCD): the launch as a whole
+    fills the chip (~1 200 workgroups at minibatch 2048), so a product needs no more - measured 16 / 32 slices per product: 259 us for
+    the launch + 40 us for the reduction of the partials, 8 slices: 250 + 32."""
     if x2.shape[0] < 16384:
         return False
     from ..g2048 import native as nv
 
-    slices = 16 if dy2.shape[1] * x2.shape[1] > 256 * 256 else 32
+    slices = 8
     if not nv.dweight_ok(dy2, x2, slices):
         return False
     sink.add_dweight(weight, bias, dy2, x2, slices, w_offset, b_offset)
