@@ -244,14 +244,19 @@ def _torch_forward(agent, boards, reduction):
     return agent.actor(feats), agent.critic(feats)
 
 
+@pytest.mark.parametrize("sink", [False, True], ids=["autograd", "sink"])
 @pytest.mark.parametrize("reduction", ["cls", "mean"])
-def test_update_path_gradients_per_tensor_at_minibatch_size(dev, reduction):
+def test_update_path_gradients_per_tensor_at_minibatch_size(dev, reduction, sink):
     """Every parameter gradient of the default-shape agent through the HIP update path (bf16 autocast, dropout 0, minibatch 2048 =
     34 816 tokens: `k_linear_ws`, `k_dweight` with column sums, attention, add+LayerNorm, the fused CLS tail for "cls" / the full last
     layer for "mean") - per TENSOR, relative to the tensor's own gradient norm, against an fp32 PyTorch backward of the same weights,
     with PyTorch's own bf16 autocast backward as the yardstick (ReLU units whose pre-activation changes sign under bf16 rounding put
     ~5 % on every tensor whichever bf16 implementation runs).  Random downstream gradients on logits and values, so nothing cancels
-    (unlike the PPO loss of the bench-shape test)."""
+    (unlike the PPO loss of the bench-shape test).  "sink": the trainer's route - a `GradSink` over a flat f32 bucket, every
+    minibatch-sized weight gradient deferred into the one grouped `g2048_dweight_jobs` launch (8 token slices) and all second-stage
+    sums in one `g2048_reduce_jobs` launch."""
+    from src.ppo.hip_ops import GradSink, grad_sink
+
     agent = default_shape_agent(dropout=0.0).to(dev)
     agent.reduction = reduction
     agent.train()
@@ -259,18 +264,25 @@ def test_update_path_gradients_per_tensor_at_minibatch_size(dev, reduction):
     boards = torch.randint(0, 12, (2048, 16), generator=g, dtype=torch.uint8).to(dev)
     gl, gv = torch.randn(2048, 4, generator=g).to(dev), torch.randn(2048, generator=g).to(dev)
 
-    def grads(model, fwd, autocast):
+    def grads(model, fwd, autocast, use_sink=False):
         model.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
             lo, va = fwd(model)
-        ((lo.float() * gl).sum() + (va.float().flatten() * gv).sum()).backward()
-        return [p.grad.detach().float().clone() for p in model.parameters()], lo.detach().float(), va.detach().float().flatten()
+        ps = list(model.parameters())
+        bucket = [torch.zeros_like(p, dtype=torch.float32) for p in ps]
+        s = GradSink({id(p): b for p, b in zip(ps, bucket)}) if use_sink else None
+        with grad_sink(s):
+            ((lo.float() * gl).sum() + (va.float().flatten() * gv).sum()).backward()
+        if use_sink:
+            assert len(s.written) > len(ps) // 2, "the sink took few gradients: not the trainer's route"
+        out = [b if (use_sink and id(p) in s.written) else p.grad.detach().float().clone() for p, b in zip(ps, bucket)]
+        return out, lo.detach().float(), va.detach().float().flatten()
 
     ref = copy.deepcopy(agent).float()
     ref.transformer._shadow, ref._head_shadow = None, None
     g32, l32, v32 = grads(ref, lambda m: _torch_forward(m, boards, reduction), False)
     g16, _, _ = grads(ref, lambda m: _torch_forward(m, boards, reduction), True)
-    gh, lh, vh = grads(agent, lambda m: m(boards, None), True)
+    gh, lh, vh = grads(agent, lambda m: m(boards, None), True, use_sink=sink)
     assert (lh - l32).abs().max().item() < 0.05 and (vh - v32).abs().max().item() < 0.05
     rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
     bad = {}
