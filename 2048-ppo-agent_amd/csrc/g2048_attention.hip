@@ -87,6 +87,17 @@ __device__ __forceinline__ bool keep_mask(const Params &P, uint64_t idx) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return (x >> 8) >= P.thr;
 }
+// The same decision for element base + c when the caller has m = (uint32_t)base * 0x9E3779B1 at hand: (base + c) * C = base * C + c * C
+// (mod 2^32), so a run of elements costs one add of a compile-time constant each instead of a 64-bit add and two of the four
+// quarter-rate v_mul_lo_u32.  SMALL (host-checked: every element index of the launch is below 2^32): the high word adds nothing
+// but seed1.  Otherwise the plain form.
+template <bool SMALL>
+__device__ __forceinline__ bool keep_rel(const Params &P, uint64_t base, uint32_t m, uint32_t c) {
+    if constexpr (!SMALL) return keep_mask(P, base + c);
+    uint32_t x = (m + c * 0x9E3779B1u) ^ (P.seed0 ^ P.seed1);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (x >> 8) >= P.thr;
+}
 
 __device__ __forceinline__ float dot_lds(const float a[HD], const float *row) {
     float s = 0.f;
@@ -423,6 +434,7 @@ __device__ __forceinline__ int key_of(int i, int hf) { return (i & 3) + 8 * (i >
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ float xhalf(float x) { return __shfl_xor(x, 32); }
 
+template <bool SMALL>
 __global__ void __launch_bounds__(64) k_attn_fwd17_mfma(Params P, uint16_t *__restrict__ o, float *__restrict__ lse) {
     mix_seed_state(P);
     __shared__ __attribute__((aligned(16))) uint16_t Vs[SK * HD];  // V of the current head, [17][32] bf16
@@ -435,6 +447,7 @@ __global__ void __launch_bounds__(64) k_attn_fwd17_mfma(Params P, uint16_t *__re
     const int rr = row_ok ? r : 0;
     const float c_log2 = P.scale * 1.4426950408889634f;
     const bool no_drop = !(P.p_drop > 0.f);
+    const uint32_t lane_km = (uint32_t)(r * 32 + 4 * hf) * 0x9E3779B1u;  // the lane's share of keep_rel's m
     const uint16_t *kb = P.k + b * P.k_sb + rr * P.k_ss + 8 * hf, *qb = P.q + b * P.q_sb + rr * P.q_ss + 8 * hf;
     const uint16_t *vb = P.v + b * P.v_sb + (lane >> 2) * P.v_ss + 8 * (lane & 3);  // rows 0..15: one 16-byte chunk per lane
     const uint16_t *v16 = P.v + b * P.v_sb + 16 * P.v_ss + 8 * (lane & 3);          // row 16: lanes 0..3
@@ -484,9 +497,10 @@ __global__ void __launch_bounds__(64) k_attn_fwd17_mfma(Params P, uint16_t *__re
         l += p[8];
         l += xhalf(l);
         const float inv = P.inv_keep / l;
-        const uint64_t base = ((uint64_t)pair * SK + r) * 32;
+        const uint64_t base = ((uint64_t)pair * SK + r) * 32 + 4 * hf;  // key_of(i, hf) = (i & 3) + 8 (i >> 2) + 4 hf
+        const uint32_t km = (uint32_t)(pair * (SK * 32)) * 0x9E3779B1u + lane_km;
         _Pragma("unroll") for (int i = 0; i < 9; ++i) {
-            const bool keep = no_drop | keep_mask(P, base + key_of(i, hf));  // (bitwise: no branch per element)
+            const bool keep = no_drop | keep_rel<SMALL>(P, base, km, (i & 3) + 8 * (i >> 2));  // (bitwise: no branch per element)
             p[i] = keep ? p[i] * inv : 0.f;
         }
         const uint4 pb0 = make_uint4(pack_bf16(p[0], p[1]), pack_bf16(p[2], p[3]), pack_bf16(p[4], p[5]), pack_bf16(p[6], p[7]));
@@ -524,16 +538,21 @@ __global__ void __launch_bounds__(64) k_attn_fwd17_mfma(Params P, uint16_t *__re
 // The operand registers of Q, K, V, dO (lane = row, 8 consecutive d per half) serve as A in one orientation and as B in the
 // other; their LDS copies ([17][32] bf16 each) only feed the three transposed gathers (9 two-byte reads per lane each).
 // 14 MFMAs per (sample, head) instead of ~2700 FMAs per lane.
-__global__ void __launch_bounds__(64) k_attn_bwd17_mfma(Params P, const uint16_t *__restrict__ dout, const float *__restrict__ lse,
+// One (sample, head) pair per wavefront, five of them resident per SIMD (82 registers; round 3): inside the update the kernel waits for HBM (its operands
+// were written a whole forward pass ago), so what pays is pairs in flight, not a register-hungry prefetch of the next head inside
+// a wave that walks several (rounds 1-2: 4 heads per wave, 146 + 32 registers = two waves per SIMD: 46.4 us per launch in the
+// update's graph, 41.2 with one head per wave).
+template <bool SMALL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5)))
+k_attn_bwd17_mfma(Params P, const uint16_t *__restrict__ dout, const float *__restrict__ lse,
                                                         uint16_t *__restrict__ dq, uint16_t *__restrict__ dk,
                                                         uint16_t *__restrict__ dv) {
     mix_seed_state(P);
     __shared__ __attribute__((aligned(16))) uint16_t Ks[SK * HD], Qs[SK * HD], Gs[SK * HD];
     __shared__ float lseS[32], delS[32];
     const int lane = threadIdx.x, r = lane & 31, hf = lane >> 5;
-    const int splits = (int)(gridDim.x / P.B);
-    const int64_t item = xcd_block(), b = item / splits;
-    const int hpw = (P.H + splits - 1) / splits, h0 = (int)(item - b * splits) * hpw, h1 = h0 + hpw < P.H ? h0 + hpw : P.H;
+    const int64_t pair = xcd_block(), b = pair / P.H;  // grid = B * H
+    const int h = (int)(pair - b * P.H);
     const bool row_ok = r < SK;
     const int rr = row_ok ? r : 0;
     const float c_log2 = P.scale * 1.4426950408889634f;
@@ -544,6 +563,8 @@ __global__ void __launch_bounds__(64) k_attn_bwd17_mfma(Params P, const uint16_t
     const uint32_t live = row_ok ? 0xFFFFFFFFu : 0u;
     auto zpad = [&](uint4 u) { return make_uint4(u.x & live, u.y & live, u.z & live, u.w & live); };
     const bool no_drop = !(P.p_drop > 0.f);
+    // the lane's share of keep_rel's m: lane = query (elements (pair * 17 + r) * 32 + key) and lane = key (... + query) * 32 + r)
+    const uint32_t lane_km1 = (uint32_t)(r * 32 + 4 * hf) * 0x9E3779B1u, lane_km2 = (uint32_t)(r + 128 * hf) * 0x9E3779B1u;
     auto fetch = [&](int h) -> Op {
         Op x;
         const uint16_t *kp = kb + h * HD, *qp = qb + h * HD, *vp = vb + h * HD, *gp = gb + h * HD;
@@ -579,32 +600,28 @@ __global__ void __launch_bounds__(64) k_attn_bwd17_mfma(Params P, const uint16_t
     };
 #define G2048_AS_OPERAND(x) Frag{make_uint4(pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7])), \
                                  make_uint4(pack_bf16(x[8], 0.f), 0u, 0u, 0u)}
-    Op nx;
-    if (h0 < h1) nx = fetch(h0);
-    for (int h = h0; h < h1; ++h) {
-        const int64_t pair = b * P.H + h;
-        Op c = nx;
+    {
+        Op c = fetch(h);
         c.k0 = zpad(c.k0); c.k1 = zpad(c.k1); c.q0 = zpad(c.q0); c.q1 = zpad(c.q1);
         c.v0 = zpad(c.v0); c.v1 = zpad(c.v1); c.g0 = zpad(c.g0); c.g1 = zpad(c.g1);
         // ---- LDS copies of K, Q, dO (row-major) for the transposed gathers; lse per query
-        wave_lds_sync();  // the previous head's gathers are done
         if (row_ok) {
             *reinterpret_cast<uint4 *>(Ks + r * HD + 8 * hf) = c.k0; *reinterpret_cast<uint4 *>(Ks + r * HD + 16 + 8 * hf) = c.k1;
             *reinterpret_cast<uint4 *>(Qs + r * HD + 8 * hf) = c.q0; *reinterpret_cast<uint4 *>(Qs + r * HD + 16 + 8 * hf) = c.q1;
             *reinterpret_cast<uint4 *>(Gs + r * HD + 8 * hf) = c.g0; *reinterpret_cast<uint4 *>(Gs + r * HD + 16 + 8 * hf) = c.g1;
             if (hf == 0) lseS[r] = c.lq;
         }
-        if (h + 1 < h1) nx = fetch(h + 1);  // the next head's operands travel behind this head's arithmetic
         const float lq2 = c.lq * 1.4426950408889634f;
         // ---- orientation 1: lane = query
         const f32x16 st = mfma2(c.k0, c.k1, c.q0, c.q1), dpt = mfma2(c.v0, c.v1, c.g0, c.g1);
         float ds[9], delta = 0.f;
         {
-            const uint64_t base = ((uint64_t)pair * SK + r) * 32;
+            const uint64_t base = ((uint64_t)pair * SK + r) * 32 + 4 * hf;
+            const uint32_t km = (uint32_t)(pair * (SK * 32)) * 0x9E3779B1u + lane_km1;
             float p[9], dp[9];
             _Pragma("unroll") for (int i = 0; i < 9; ++i) {
                 const bool valid = i < 8 || hf == 0;
-                const bool keep = no_drop | keep_mask(P, base + key_of(i, hf));
+                const bool keep = no_drop | keep_rel<SMALL>(P, base, km, (i & 3) + 8 * (i >> 2));
                 p[i] = valid ? exp2f(st[i] * c_log2 - lq2) : 0.f;
                 dp[i] = (valid && keep) ? dpt[i] * P.inv_keep : 0.f;
                 delta = fmaf(p[i], dp[i], delta);
@@ -619,10 +636,12 @@ __global__ void __launch_bounds__(64) k_attn_bwd17_mfma(Params P, const uint16_t
         // ---- orientation 2: lane = key, register i = query key_of(i, hf)
         const f32x16 s2 = mfma2(c.q0, c.q1, c.k0, c.k1), dp2 = mfma2(c.g0, c.g1, c.v0, c.v1);
         float ds2[9], pd2[9];
+        const uint64_t base2 = (uint64_t)pair * (SK * 32) + r + 128 * hf;  // query key_of(i, hf): 32 x ((i & 3) + 8 (i >> 2)) more
+        const uint32_t km2 = (uint32_t)(pair * (SK * 32)) * 0x9E3779B1u + lane_km2;
         _Pragma("unroll") for (int i = 0; i < 9; ++i) {
             const bool valid = i < 8 || hf == 0;
             const int qi = valid ? key_of(i, hf) : 0;
-            const bool keep = no_drop | keep_mask(P, ((uint64_t)pair * SK + qi) * 32 + r);
+            const bool keep = no_drop | keep_rel<SMALL>(P, base2, km2, 32 * ((i & 3) + 8 * (i >> 2)));
             const float p = valid ? exp2f(s2[i] * c_log2 - lseS[qi] * 1.4426950408889634f) : 0.f;
             const float dp = (valid && keep) ? dp2[i] * P.inv_keep : 0.f;
             ds2[i] = p * (dp - delS[qi]) * P.scale;
@@ -656,6 +675,8 @@ inline int done() {
 }
 // G2048_ATTN_SCALAR=1 keeps the scalar kernels (17-token: one lane per query row; CLS row: one lane per pair) (read per call: no
 // latch, no library state)
+// every dropout element index (pair * 17 + query) * 32 + key of the launch, padding lanes included, stays below 2^32
+inline bool small_indices(int64_t pairs) { return pairs <= (int64_t)((1ull << 32) / (SK * 32)) - 2; }
 inline bool use_mfma17() {
     const char *e = getenv("G2048_ATTN_SCALAR");
     return !(e && e[0] == '1');
@@ -672,9 +693,9 @@ extern "C" int g2048_attn_fwd(const void *q, const void *k, const void *v, void 
     const int64_t pairs = B * H;
     if (Sq == SK && use_mfma17())
         // heads per wave: measured at 2048 boards x 8 heads inside the update's graph, 3 launches: 8 / 4 / 2 / 1 heads per wave =
-        // 69.8 / 59.6 / 61.2 / 53.6 us (the backward is flat: 128.7 / 131.5 / 133.1 / 135.1)
-        hipLaunchKernelGGL(k_attn_fwd17_mfma, dim3((unsigned)(B * (H % 8 == 0 ? 8 : (H % 2 == 0 ? 2 : 1)))), dim3(64), 0, (hipStream_t)stream, P, (uint16_t *)o,
-                           lse);
+        // 69.8 / 59.6 / 61.2 / 53.6 us (the backward, then at two waves per SIMD, was flat: 128.7 / 131.5 / 133.1 / 135.1; see k_attn_bwd17_mfma)
+        hipLaunchKernelGGL(small_indices(pairs) ? k_attn_fwd17_mfma<true> : k_attn_fwd17_mfma<false>,
+                           dim3((unsigned)(B * (H % 8 == 0 ? 8 : (H % 2 == 0 ? 2 : 1)))), dim3(64), 0, (hipStream_t)stream, P, (uint16_t *)o, lse);
     else if (Sq == SK)
         hipLaunchKernelGGL(k_attn_fwd17, dim3((unsigned)((pairs + PAIRS - 1) / PAIRS)), dim3(64), 0, (hipStream_t)stream, P,
                            (uint16_t *)o, lse);
@@ -696,8 +717,8 @@ extern "C" int g2048_attn_bwd(const void *q, const void *k, const void *v, const
         return G2048_EINVAL;
     const int64_t pairs = B * H;
     if (Sq == SK && use_mfma17())
-        hipLaunchKernelGGL(k_attn_bwd17_mfma, dim3((unsigned)(B * (H % 2 == 0 ? 2 : 1))), dim3(64), 0, (hipStream_t)stream, P,
-                           (const uint16_t *)dout, lse, (uint16_t *)dq, (uint16_t *)dk, (uint16_t *)dv);
+        hipLaunchKernelGGL(small_indices(pairs) ? k_attn_bwd17_mfma<true> : k_attn_bwd17_mfma<false>, dim3((unsigned)pairs),
+                           dim3(64), 0, (hipStream_t)stream, P, (const uint16_t *)dout, lse, (uint16_t *)dq, (uint16_t *)dk, (uint16_t *)dv);
     else if (Sq == SK)
         hipLaunchKernelGGL(k_attn_bwd17, dim3((unsigned)((pairs + PAIRS - 1) / PAIRS)), dim3(64), 0, (hipStream_t)stream, P,
                            (const uint16_t *)dout, lse, (uint16_t *)dq, (uint16_t *)dk, (uint16_t *)dv);
