@@ -676,7 +676,11 @@ inline int done() {
 // G2048_ATTN_SCALAR=1 keeps the scalar kernels (17-token: one lane per query row; CLS row: one lane per pair) (read per call: no
 // latch, no library state)
 // every dropout element index (pair * 17 + query) * 32 + key of the launch, padding lanes included, stays below 2^32
-inline bool small_indices(int64_t pairs) { return pairs <= (int64_t)((1ull << 32) / (SK * 32)) - 2; }
+// (G2048_ATTN_WIDE_INDEX=1 forces the 64-bit form, which no realistic batch reaches: the tests compare the two bit for bit)
+inline bool small_indices(int64_t pairs) {
+    const char *e = getenv("G2048_ATTN_WIDE_INDEX");
+    return pairs <= (int64_t)((1ull << 32) / (SK * 32)) - 2 && !(e && e[0] == '1');
+}
 inline bool use_mfma17() {
     const char *e = getenv("G2048_ATTN_SCALAR");
     return !(e && e[0] == '1');

@@ -302,6 +302,41 @@ def test_mfma_attention_equals_scalar_attention(dev, monkeypatch):
                 assert torch.equal((o1 == 0).all(-1), (o2 == 0).all(-1))
 
 
+def test_mfma_attention_dropout_index_forms_agree_bitwise(dev, monkeypatch):
+    """The MFMA attention kernels take the dropout decision of element base + c from (uint32)base * C + c * C when every element
+    index of the launch is below 2^32 (host-checked) and from the plain 64-bit form otherwise (more than 7.9 M (sample, head) pairs:
+    not reachable in a test).  G2048_ATTN_WIDE_INDEX=1 forces the 64-bit form: outputs, log-sum-exps and gradients must be equal
+    bit for bit, with and without the device-resident seed word."""
+    from src.g2048 import native as nv
+
+    H, hd, S = 8, 32, 17
+    W, hw = 3 * H * hd, H * hd
+    torch.manual_seed(5)
+    state = torch.tensor([0x1234_5678_9ABC_DEF0], dtype=torch.int64, device=dev)
+    for B in (3, 777):
+        qkv = (torch.randn(B, S, W, device=dev) * 1.5).to(torch.bfloat16)
+        do = torch.randn(B, S, hw, device=dev).to(torch.bfloat16)
+        base = qkv.data_ptr()
+        for seed_state in (0, state.data_ptr()):
+            res = {}
+            for wide in ("0", "1"):
+                monkeypatch.setenv("G2048_ATTN_WIDE_INDEX", wide)
+                o = torch.empty((B, S, hw), dtype=torch.bfloat16, device=dev)
+                lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+                nv.attn_fwd(base, base + 2 * hw, base + 4 * hw, o, lse, B, H, S, (S * W, W) * 3, hd ** -0.5, 0.3, 99, seed_state)
+                dqkv = torch.empty_like(qkv)
+                db = dqkv.data_ptr()
+                nv.attn_bwd(base, base + 2 * hw, base + 4 * hw, do, lse, db, db + 2 * hw, db + 4 * hw, B, H, S, (S * W, W) * 3,
+                            hd ** -0.5, 0.3, 99, seed_state)
+                res[wide] = (o, lse, dqkv)
+            monkeypatch.delenv("G2048_ATTN_WIDE_INDEX")
+            for a, b in zip(res["0"], res["1"]):
+                assert torch.equal(a, b), (B, seed_state != 0)
+            o0, lse0 = torch.empty_like(res["0"][0]), torch.empty_like(res["0"][1])
+            nv.attn_fwd(base, base + 2 * hw, base + 4 * hw, o0, lse0, B, H, S, (S * W, W) * 3, hd ** -0.5, 0.0, 99, seed_state)
+            assert not torch.equal(o0, res["0"][0])  # dropout was on
+
+
 def test_cls_attention_row_coalesced_equals_scalar(dev, monkeypatch):
     """The CLS-row attention (Sq = 1) with a 32-lane group per sample and 512-byte K/V row fetches (default for 8 heads) vs
     one lane per (sample, head) pair (G2048_ATTN_SCALAR=1), same inputs and dropout seed, K/V read from the packed

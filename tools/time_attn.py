@@ -1,6 +1,7 @@
 """Time g2048_attn_fwd / g2048_attn_bwd alone at the update's shape (2048 boards x 8 heads x 17 tokens, packed in_proj
 output, dropout 0.1) - for A/B runs of kernel variants: `G2048_LIB=tools/_build/<variant>.so python tools/time_attn.py`.
-Prints one line; with --check also the maximum difference of dq/dk/dv to the library in lib/ run in a child process."""
+Prints one line: both times and two checksums of dq/dk/dv (equal checksums across libraries on the same inputs = bitwise-equal arithmetic
+as far as a sum can tell; the parity tests are tests/test_gpu_ppo.py)."""
 import os
 import sys
 
