@@ -31,21 +31,25 @@ class FlatAdamWStep:
                     return False
         return True
 
-    def __init__(self, optimizer: torch.optim.AdamW, device):
+    def __init__(self, optimizer: torch.optim.AdamW, device, first=()):
+        """``first``: parameters whose slices come FIRST in the flat buffers, in optimiser order (the trainer's early all-reduce
+        bucket: gradients that are final before the rest of the backward has run); ``self.n_first`` = elements they occupy."""
         if not self.supports(optimizer, device):
             raise ValueError("FlatAdamWStep needs a torch.optim.AdamW over contiguous f32 parameters on the HIP device")
         self.optimizer, self.device = optimizer, torch.device(device)
-        self.params, self.group_of = [], []
-        for gi, g in enumerate(optimizer.param_groups):
-            for p in g["params"]:
-                if p.requires_grad:
-                    self.params.append(p)
-                    self.group_of.append(gi)
+        entries = [(p, gi) for gi, g in enumerate(optimizer.param_groups) for p in g["params"] if p.requires_grad]
+        first_ids = {id(p) for p in first}
+        entries = [e for e in entries if id(e[0]) in first_ids] + [e for e in entries if id(e[0]) not in first_ids]
+        self.params, self.group_of = [e[0] for e in entries], [e[1] for e in entries]
+        n_first_params = sum(1 for p in self.params if id(p) in first_ids)
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
             n += (p.numel() + 3) // 4 * 4  # every tensor starts on a 16-byte boundary of the flat buffers
         self.numel = n
+        self.n_first = self.offsets[n_first_params] if n_first_params < len(self.params) else n
+        if n_first_params == 0:
+            self.n_first = 0
         z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
         self.grad, self.exp_avg, self.exp_avg_sq = z(), z(), z()
         self.steps = torch.zeros(len(self.params), dtype=torch.float32, device=self.device)
@@ -83,6 +87,13 @@ class FlatAdamWStep:
         if self.steps.numel() and float(self.steps.min()) != float(self.steps.max()):
             raise ValueError("FlatAdamWStep: the optimizer state holds different step counts per parameter "
                              f"({float(self.steps.min()):.0f}..{float(self.steps.max()):.0f}); g2048_opt_step keeps one count for all")
+
+    def reset_state(self):
+        """A fresh optimiser state (zero moments, step 0) in the flat buffers ``optimizer.state`` already points at."""
+        with torch.no_grad():
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            self.steps.zero_()
 
     def adopt_shadows(self, shadows):
         """Keep bf16 shadow copies of parameters up to date from inside the optimiser kernel.  ``shadows``: objects with

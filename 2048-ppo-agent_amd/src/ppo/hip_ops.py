@@ -115,9 +115,15 @@ class GradSink:
 
     active = None
 
-    def __init__(self, targets: dict):
+    def __init__(self, targets: dict, early=None, on_early=None):
+        """``early``: ids of parameters whose gradients are final long before the backward pass ends (the fused CLS tail: the last
+        layer's out_proj .. both heads, 1.4 M of the default model's 3.96 M parameters); their jobs are kept apart, and when the
+        node that produces them says so (``early_complete``) they are summed by a launch of their own and ``on_early()`` runs --
+        the trainer starts the all-reduce of that part of the bucket there, under the backward of the three full layers."""
         self.targets, self.jobs, self.written = targets, [], set()
         self.dw_jobs = []  # minibatch-sized weight gradients deferred to flush(): one grouped launch (g2048_dweight_jobs)
+        self.early = frozenset(early or ())
+        self.early_jobs, self.on_early, self.early_done = [], on_early, False
 
     def takes(self, *params) -> bool:
         return all(p is not None and id(p) in self.targets for p in params)
@@ -127,8 +133,21 @@ class GradSink:
         column 0; the tensor is kept alive until ``flush``); ``transpose_rows`` R: the summed [R][n / R] matrix is stored
         transposed."""
         dst = self.targets[id(param)].view(-1)[dst_offset:dst_offset + n]
-        self.jobs.append((src, dst, part_stride, n, parts, transpose_rows))
+        (self.early_jobs if (id(param) in self.early and not self.early_done) else self.jobs).append(
+            (src, dst, part_stride, n, parts, transpose_rows))
         self.written.add(id(param))
+
+    def early_complete(self):
+        """Called by the node that owns the early parameters once all their jobs are registered: sum them now (one launch) and
+        tell the owner.  A no-op unless EVERY early parameter has been written (else ``flush`` sums everything at the end)."""
+        if self.early_done or not self.early or not self.early <= self.written:
+            return
+        from ..g2048 import native as nv
+
+        nv.reduce_jobs(self.early_jobs)
+        self.early_jobs, self.early_done = [], True
+        if self.on_early is not None:
+            self.on_early()
 
     def add_dweight(self, weight, bias, dy2: torch.Tensor, x2: torch.Tensor, slices: int, w_offset: int = 0, b_offset: int = 0):
         """dW = dy2^T x2 (and db = column sums of dy2) computed at ``flush`` together with every other deferred product; the partials
@@ -147,8 +166,8 @@ class GradSink:
         if self.dw_jobs:
             nv.dweight_jobs(self.dw_jobs)
             self.dw_jobs = []
-        nv.reduce_jobs(self.jobs)
-        self.jobs = []
+        nv.reduce_jobs(self.early_jobs + self.jobs)
+        self.jobs, self.early_jobs = [], []
 
 
 class grad_sink:
@@ -977,8 +996,10 @@ class TailPlan:
         key = (int(M), str(device))
         buf = self.cache.get(key)
         if buf is None or getattr(buf, "busy", False):
-            # busy: a forward whose backward never ran still owns the cached set (e.g. two forwards before one backward): this
-            # call gets a private one instead of overwriting what that backward would read
+            # busy: a forward whose autograd graph is still alive and whose backward has not run owns the cached set (two forwards
+            # before one backward): this call gets a private one instead of overwriting what that backward would read.  The cached
+            # set itself is never replaced -- a captured hipGraph holds its raw pointers -- and it is released when its backward
+            # runs OR when the graph that references it is dropped (``_ClsTailHeads.forward`` ties ``busy`` to the node's lifetime)
             fresh = nv.TailBuffers(M, device)
             if buf is None:
                 self.cache[key] = fresh
@@ -1000,13 +1021,21 @@ class TailPlan:
         return nv.tail_weights_t(t), t
 
 
+def _release_tail_buffers(buf_ref, gen: int):
+    buf = buf_ref()
+    if buf is not None and getattr(buf, "gen", 0) == gen:
+        buf.busy = False
+
+
 class _ClsTailHeads(torch.autograd.Function):
     """``(logits, values)`` from the CLS rows after the last layer's attention: out_proj + dropout + residual + LayerNorm, the
     feed-forward block + dropout + residual, actor and critic heads -- ``g2048_cls_tail_fwd`` forward, ``g2048_cls_tail_bwd`` +
     ``g2048_dweight_t`` backward: 3 launches where the unfused nodes needed ~55.  o bf16 [M, 1, 256] (attention output), x f32
     [M, 1, 256] (CLS rows of the residual stream, read in place through their row stride); ``params``: the f32 masters in
     ``TAIL_PARAM_ORDER`` (inputs only so that autograd can take their gradients when no ``GradSink`` is active).
-    One minibatch in flight per module: the buffers between forward and backward are cached per minibatch size."""
+    One minibatch in flight per module: the buffers between forward and backward are cached per minibatch size.  The returned
+    ``logits`` / ``values`` are tensors OF that cached set: the next forward at the same minibatch size overwrites them (unless this
+    one's backward is still pending, see ``TailPlan.buffers``) -- a caller that keeps them across minibatches clones them."""
 
     @staticmethod
     def forward(ctx, o, x, plan, *params):
@@ -1020,6 +1049,11 @@ class _ClsTailHeads(torch.autograd.Function):
         seed = _seed_pair(o2, plan.p_drop)
         logits, values = nv.cls_tail_fwd(o2, xr.data_ptr(), row_stride, W, buf, plan.eps, plan.p_drop, *seed)
         buf.busy = True
+        # a forward that is never followed by a backward (a diagnostic evaluate_actions with gradients on, an exception in the
+        # loss) must not hold the cached set forever: when this node dies without having run, the set is free again.  The
+        # generation keeps a late finaliser of an OLD node from releasing a set that a newer forward owns by then.
+        buf.gen = gen = getattr(buf, "gen", 0) + 1
+        weakref.finalize(ctx, _release_tail_buffers, weakref.ref(buf), gen)
         ctx.plan, ctx.buf, ctx.seed, ctx.keep = plan, buf, seed, (keep, xr, o2)
         ctx.x_shape, ctx.o_shape = tuple(x.shape), tuple(o.shape)
         ctx.set_materialize_grads(False)
@@ -1062,6 +1096,8 @@ class _ClsTailHeads(torch.autograd.Function):
         else:
             s = lnp.sum(0)
             grads["ln_g"], grads["ln_b"] = s[:256].to(P["ln_g"].dtype), s[256:].to(P["ln_b"].dtype)
+        if sink is not None:
+            sink.early_complete()  # everything this node produces is registered: an early all-reduce bucket may go now
         # (views of the cached buffers: the nodes that consume them run in this same backward pass)
         do_out = d_o.view(ctx.o_shape) if ctx.needs_input_grad[0] else None
         dx_out = dx.view(ctx.x_shape) if ctx.needs_input_grad[1] else None

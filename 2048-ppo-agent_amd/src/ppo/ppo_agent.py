@@ -146,6 +146,19 @@ class PPOAgent(_ActorCritic):
         plan = TailPlan(params, dense, transposed, self._tail_buffers, eps, p_drop)
         return _ClsTailHeads.apply(o, x_cls, plan, *[params[k] for k in TAIL_PARAM_ORDER])
 
+    def early_grad_parameters(self):
+        """Parameters whose gradients are complete as soon as the fused CLS tail's backward has run (``TAIL_PARAM_ORDER``: the last
+        layer's out_proj, norm2, linear1, linear2 and both heads) -- the trainer's early all-reduce bucket; [] when the update
+        does not go through that node."""
+        if not self._tail_heads_ok() or self.transformer.encoder.norm is not None:
+            return []
+        last = self.transformer.encoder.layers[-1]
+        if last.linear1.out_features != 1024 or self.transformer.d_model != 256:
+            return []
+        mods = [last.self_attn.out_proj, last.norm2, last.linear1, last.linear2] + [m for h in (self.actor, self.critic)
+                                                                                    for m in h if isinstance(m, nn.Linear)]
+        return [p for m in mods for p in m.parameters()]
+
     def forward(self, observations: torch.Tensor, action_mask: torch.Tensor = None):
         w = self.input_embedding.weight
         if self.transformer.embed_boards_ok(observations, w) and self._tail_heads_ok():

@@ -146,14 +146,23 @@ class _GraphedFwdBwd:
         seed_word = graph_seed_state(dev)  # allocated outside the capture
         # capture.capture(): thread-local error mode, and no cyclic garbage collection while the stream is capturing (a
         # collection that finalises an earlier trainer's CUDAGraph / graph pool on this thread aborts the process: capture.py)
-        with capture_graph(self.graph):
-            seed_word.add_(1)  # new dropout masks on every replay (the HIP kernels read it at run time)
-            self.out = self._fwd_bwd()
-            if trainer._flat_grad is not None:
-                trainer._collect_grads(point_grads=False)  # graph-owned gradients -> all-reduce bucket, one copy
-                if capture_allreduce:
-                    trainer._allreduce_bucket()  # the step's one collective as a node of the graph
+        trainer._capturing_allreduce = trainer._early_armed = bool(capture_allreduce)
+        try:
+            with capture_graph(self.graph):
+                seed_word.add_(1)  # new dropout masks on every replay (the HIP kernels read it at run time)
+                self.out = self._fwd_bwd()
+                if trainer._flat_grad is not None:
+                    trainer._collect_grads(point_grads=False)  # graph-owned gradients -> all-reduce bucket, one copy
+                    if capture_allreduce:
+                        trainer._allreduce_bucket()  # the step's collective(s) as nodes of the graph
+        finally:
+            trainer._capturing_allreduce = trainer._early_armed = False
+            trainer._early_work = None
         Bf16Shadow.invalidate_all()  # nothing was copied during the capture itself
+        # parameters that received no gradient inside the capture: a replay leaves zeros in their bucket slices (the captured
+        # ``v.zero_()``), and after it every ``p.grad`` points somewhere, so the list cannot be recomputed from ``p.grad``; the
+        # optimiser step after a replay takes it from here (torch's AdamW leaves such parameters alone: no decay, no moments)
+        self.no_grad = list(getattr(trainer, "_no_grad", ())) if trainer._flat_grad is not None else []
         # the gradients the replay writes (graph pool) / the tensors the optimizer reads after a replay
         self.grads = [p.grad for p in trainer.agent.parameters()]
         if trainer._flat_grad is not None:
@@ -231,8 +240,13 @@ class PPOTrainer:
         # distance from the fp32 forward, i.e. the same distance the update's own forward has) is documented in
         # INTEGRATION.md.  ``rollout_amp=False`` or G2048_ROLLOUT_FP32=1 keeps the reference's fp32 rollout;
         # G2048_ROLLOUT_AMP=0/1 (round-2 switch) is still honoured.
+        implied = rollout_amp is None and not os.environ.get("G2048_ROLLOUT_AMP", "").strip()
         rollout_amp = resolve_rollout_amp(rollout_amp, mixed_precision)
         self.rollout_amp = bool(rollout_amp) and self.use_amp
+        if self.rollout_amp and implied:
+            logger.warning("rollout forward runs in %s (implied by mixed_precision; the reference rolls out in fp32): stored "
+                           "log-probs / values are at autocast distance from the fp32 forward.  G2048_ROLLOUT_FP32=1 or "
+                           "rollout_amp=False restores the reference's precision.", mixed_precision)
         # How collect_rollouts gathers experience.  "episodes" (default) is the reference: lock-step batches of complete
         # episodes (src/runs/batch_runner.py:117), finished envs idle until the slowest one ends.  "fixed_horizon" is the
         # throughput mode: every env steps rollout_horizon times per batch, an env whose episode ends starts the next one at
@@ -273,12 +287,25 @@ class PPOTrainer:
             allreduce_in_graph = os.environ.get("G2048_ALLREDUCE_IN_GRAPH", "0").strip().lower() in ("1", "true", "yes", "on")
         self.allreduce_in_graph = bool(allreduce_in_graph) and self.world > 1 and self.device.type == "cuda"
         self.allreduce_in_graph_fallback = None
+        # Two all-reduce buckets (world > 1; G2048_ALLREDUCE_BUCKETS=1 keeps the single one, =2 forces the split also on one
+        # rank, for tests): the parameters whose gradients are final after the first third of the backward (the agent's
+        # ``early_grad_parameters()``: the fused CLS tail, 1.4 M of 3.96 M) come FIRST in the flat bucket; where the collective
+        # can start mid-backward (eager update, or captured inside the hipGraph) their slice is summed and all-reduced while the
+        # three full layers' backward still runs.  Same result as one bucket, element for element (a sum over ranks per element).
+        nb = os.environ.get("G2048_ALLREDUCE_BUCKETS", "").strip()
+        early = list(getattr(self.agent, "early_grad_parameters", lambda: [])()) if (nb == "2" or (nb != "1" and self.world > 1)) else []
+        self._early_params = [p for p in early if p.requires_grad]
+        self._split_always = nb == "2"
+        self._early_n, self._early_work, self._early_launched = 0, None, 0
+        # armed only around a forward+backward whose gradients ARE all-reduced afterwards (update_policy's eager minibatch, a capture
+        # that includes the collectives): a stray backward (graph warm-up, a test calling _loss_backward) must not start one
+        self._early_armed = False
         # clip + AdamW + GradScaler bookkeeping as three launches over flat buffers (g2048_opt_step) for the reference's
         # default optimiser on the device; anything else (LAMB, Adam, CPU) takes the PyTorch calls of the reference
         self._flat_step = None
         if os.environ.get("G2048_FLAT_OPT", "1").strip().lower() not in ("0", "false", "no", "off") \
                 and FlatAdamWStep.supports(self.optimizer, self.device):
-            self._flat_step = FlatAdamWStep(self.optimizer, self.device)
+            self._flat_step = FlatAdamWStep(self.optimizer, self.device, first=self._early_params)
         if self.world > 1 or self._flat_step is not None:
             self._bind_flat_grads()
         if self.world > 1:
@@ -326,12 +353,17 @@ class PPOTrainer:
         if self._flat_step is not None:  # the optimiser kernel's gradient buffer IS the bucket
             self._params, self._flat_grad = self._flat_step.params, self._flat_step.grad
             self._flat_views = self._flat_step.grad_views
+            self._early_n = self._flat_step.n_first
             self._flat_grad.zero_()
             for p in self._params:
                 p.grad = None
             self._sink_targets = {id(p): v for p, v in zip(self._params, self._flat_views)}
+            self._alloc_comm_buf()
             return
         self._params = [p for p in self.agent.parameters() if p.requires_grad]
+        early_ids = {id(p) for p in self._early_params}
+        self._params = [p for p in self._params if id(p) in early_ids] + [p for p in self._params if id(p) not in early_ids]
+        self._early_n = sum(p.numel() for p in self._params if id(p) in early_ids)
         total = sum(p.numel() for p in self._params)
         self._flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
         self._flat_views, off = [], 0
@@ -341,6 +373,15 @@ class PPOTrainer:
             p.grad = None
             off += n
         self._sink_targets = {id(p): v for p, v in zip(self._params, self._flat_views)}
+        self._alloc_comm_buf()
+
+    def _alloc_comm_buf(self):
+        """The bf16 wire buffer of the all-reduce, allocated BEFORE any stream capture: allocated lazily inside the capture it
+        lived in that graph's private pool while eager collectives and later graphs kept using it."""
+        if self.world > 1 and self.allreduce_dtype == torch.bfloat16 and self._flat_grad is not None and (
+                self._comm_buf is None or self._comm_buf.device != self._flat_grad.device
+                or self._comm_buf.numel() != self._flat_grad.numel()):
+            self._comm_buf = torch.empty_like(self._flat_grad, dtype=torch.bfloat16)
 
     def _collect_grads(self, point_grads: bool = True):
         src, dst = [], []
@@ -374,16 +415,57 @@ class PPOTrainer:
             self._allreduce_bucket()
 
     def _allreduce_bucket(self):
-        """mean over ranks of the flat gradient bucket, in place: ONE collective (f32, or bf16 on the wire)."""
+        """mean over ranks of the flat gradient bucket, in place: ONE collective (f32, or bf16 on the wire) -- or, when the
+        early part of the bucket is already under way (``_start_early_allreduce``), the rest of it plus a wait for that part."""
+        lo = 0
+        if self._early_work is not None:
+            lo = self._early_n
+        elif 0 < self._early_n < self._flat_grad.numel() and self._two_buckets_now() and (
+                self.device.type != "cuda" or self._split_always):
+            # nothing to hide it under at this point: on the device a replayed graph (or a backward without the sink) is followed
+            # by ONE collective; the host path (gloo, the CPU tests) runs the same two-bucket protocol so that it is covered
+            self._start_early_allreduce()
+            lo = self._early_n
+        grad = self._flat_grad[lo:] if lo else self._flat_grad
         if self.allreduce_dtype == torch.bfloat16:
-            if self._comm_buf is None or self._comm_buf.device != self._flat_grad.device:
-                self._comm_buf = torch.empty_like(self._flat_grad, dtype=torch.bfloat16)
-            self._comm_buf.copy_(self._flat_grad)
-            dist.all_reduce(self._comm_buf, op=dist.ReduceOp.SUM, group=self._group)
-            self._flat_grad.copy_(self._comm_buf)
+            self._alloc_comm_buf()  # (no-op: _bind_flat_grads allocated it, outside any capture)
+            comm = self._comm_buf[lo:] if lo else self._comm_buf
+            comm.copy_(grad)
+            dist.all_reduce(comm, op=dist.ReduceOp.SUM, group=self._group)
+            grad.copy_(comm)
         else:
-            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM, group=self._group)
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self._group)
+        if self._early_work is not None:
+            self._early_work.wait()
+            self._early_work = None
+            if self.allreduce_dtype == torch.bfloat16:
+                self._flat_grad[:lo].copy_(self._comm_buf[:lo])
         self._flat_grad.div_(self.world)
+
+    def _two_buckets_now(self) -> bool:
+        """Whether a collective may start at this point of the step: not while a hipGraph is being captured unless the capture
+        includes the collectives (a replay runs no Python; the eager collective after it is then a single one)."""
+        if self.world <= 1 or not self._early_n or not self._early_armed:
+            return False
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        return (not capturing) or bool(getattr(self, "_capturing_allreduce", False))
+
+    def _start_early_allreduce(self):
+        """SUM over ranks of the first ``_early_n`` elements of the bucket, asynchronously (the process group's own stream /
+        thread); ``_allreduce_bucket`` waits for it.  Called from ``GradSink.early_complete`` on autograd's worker thread, right
+        after the launch that summed those gradients into the bucket (the collective is ordered behind it on the device)."""
+        n = self._early_n
+        if self.allreduce_dtype == torch.bfloat16:
+            self._alloc_comm_buf()
+            self._comm_buf[:n].copy_(self._flat_grad[:n])
+            self._early_work = dist.all_reduce(self._comm_buf[:n], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+        else:
+            self._early_work = dist.all_reduce(self._flat_grad[:n], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+        self._early_launched += 1
+
+    def _on_early_grads(self):
+        if self._two_buckets_now():
+            self._start_early_allreduce()
 
     def _global_max(self, value: int) -> int:
         t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
@@ -538,7 +620,10 @@ class PPOTrainer:
         if fused:
             out = sums if (scale is not None or not self.use_amp) else self.scaler.scale(sums)
             # weight / bias / LayerNorm gradients: first-stage partials only, summed into the bucket by ONE launch at the end
-            sink = GradSink(self._sink_targets) if (self.grad_sink and self._flat_grad is not None) else None
+            sink = None
+            if self.grad_sink and self._flat_grad is not None:
+                early = [id(p) for p in self._early_params] if 0 < self._early_n < self._flat_grad.numel() else None
+                sink = GradSink(self._sink_targets, early=early, on_early=self._on_early_grads if early else None)
             with grad_sink(sink):
                 out.backward(self._loss_selector())
             if sink is not None and sink.written:  # autograd never saw these: point .grad at what the sink wrote
@@ -555,6 +640,15 @@ class PPOTrainer:
             stats = torch.stack([pl.mean(), vl.mean(), el.mean(), loss.detach()]).double()
             kl = (old_lp - new_lp).mean().double().reshape(1)
         return stats, kl
+
+    def _armed_loss_backward(self, sample: dict):
+        """update_policy's eager minibatch: the early bucket's all-reduce may start from inside this backward."""
+        self._early_armed = self.world > 1
+        try:
+            return self._loss_backward(**sample)
+        except BaseException:
+            self._early_armed, self._early_work = False, None
+            raise
 
     def _loss_selector(self) -> torch.Tensor:
         """d(total)/d(sums): picks the total loss out of the fused loss kernel's five means."""
@@ -582,6 +676,13 @@ class PPOTrainer:
                 masks = (masks.unsqueeze(-1) & bits) != 0
         return obs, actions, masks, batch["log_probs"], batch["advantages"], batch["returns"]
 
+    def per_rank_samples_per_epoch(self):
+        """This rank's share of the reference's ONE subset of ``max_samples_per_epoch`` per epoch (None: no subset)."""
+        per_rank = self.max_samples_per_epoch
+        if per_rank is not None and self.world > 1:
+            per_rank = -(-int(per_rank) // self.world)
+        return per_rank
+
     # ------------------------------------------------------------------ update
     def update_policy(self, batch_size: int = 64, n_epochs: int = 4) -> Dict[str, float]:
         """``n_epochs`` passes of minibatch PPO over the rollout buffer; early stop when mean(old - new log-prob)
@@ -593,9 +694,7 @@ class PPOTrainer:
         # the reference draws ONE subset of max_samples_per_epoch from the whole buffer (src/ppo/data_loader.py:73-101);
         # sharded, every rank draws its 1/world share of it from its own slice of the buffer, so the global number of
         # samples (and of optimiser steps) per epoch is the single-device one
-        per_rank = self.max_samples_per_epoch
-        if per_rank is not None and self.world > 1:
-            per_rank = -(-int(per_rank) // self.world)
+        per_rank = self.per_rank_samples_per_epoch()
         dataset = PPODataset(data, gamma=self.gamma, lambda_gae=self.lambda_gae, max_samples_per_epoch=per_rank,
                              shuffle_on_reset=self.shuffle_on_reset, group=self._group)
         batches = DeviceBatches(dataset, batch_size, drop_last=True)
@@ -627,7 +726,7 @@ class PPOTrainer:
                         sample = batches.gather_packed(idx)
                         if self.use_hip_graph and full:
                             graphed = self._build_graph(gkey, batch_size, sample)
-                        stats, kl = graphed.run(sample) if graphed is not None else self._loss_backward(**sample)
+                        stats, kl = graphed.run(sample) if graphed is not None else self._armed_loss_backward(sample)
                 else:
                     obs, actions, masks, old_lp, adv, ret = self._unpack_batch(batches.gather(idx),
                                                                                packed=self._fused_loss_ok())
@@ -636,8 +735,12 @@ class PPOTrainer:
                     if self.use_hip_graph and full:
                         gkey = (batch_size, obs.dtype, tuple(obs.shape[1:]))
                         graphed = self._graphs.get(gkey) or self._build_graph(gkey, batch_size, sample)
-                    stats, kl = graphed.run(sample) if graphed is not None else self._loss_backward(**sample)
+                    stats, kl = graphed.run(sample) if graphed is not None else self._armed_loss_backward(sample)
+                self._early_armed = self.world > 1  # (the collective below may itself split the bucket: CPU / non-sink path)
                 self._allreduce_grads(collective=not (graphed is not None and graphed.allreduce_captured))
+                self._early_armed = False
+                if graphed is not None and self._flat_grad is not None:
+                    self._no_grad = list(graphed.no_grad)  # (see _GraphedFwdBwd: not recoverable from p.grad after a replay)
                 if self._flat_step is not None:
                     self._flat_step.adopt_shadows(list(Bf16Shadow._live))  # (no-op once they are adopted)
                     self._flat_step.step(self.max_grad_norm, self.scaler if self.use_amp else None,
@@ -734,7 +837,14 @@ class PPOTrainer:
             except Exception as e:  # keep training with a fresh optimizer, as the reference does
                 logger.warning("Failed to load optimizer state: %s", e)
             if self._flat_step is not None:
-                self._flat_step.adopt_state()
+                try:
+                    self._flat_step.adopt_state()
+                except ValueError as e:
+                    # e.g. a plain-AdamW checkpoint whose parameters disagree on the step count: like a state that failed to
+                    # load at all, keep training with a fresh optimizer state (the reference does, ppo_trainer.py:570-582); the
+                    # rest of the restore below still runs
+                    logger.warning("Optimizer state not usable by the flat step (%s); continuing with a fresh state", e)
+                    self._flat_step.reset_state()
         self.total_timesteps = ckpt.get("total_timesteps", 0)
         self.total_epochs = ckpt.get("total_epochs", 0)
         self.total_update_steps = ckpt.get("total_update_steps", 0)

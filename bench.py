@@ -401,6 +401,7 @@ def main():
                    "boards_per_gpu": args.boards, "global_boards": global_boards, "train_batch": args.train_batch,
                    "update_epochs": args.epochs, "max_samples_per_epoch": TRAINER_CFG["max_samples_per_epoch"],
                    "max_samples_per_epoch_is": "global (each rank draws its 1/N share), as the reference's single subset",
+                   "max_samples_per_epoch_per_rank": trainer.per_rank_samples_per_epoch(),
                    "rollout_mode": "episodes (reference lock-step semantics)",
                    "rng_mode": "partitionable", "parallelism": f"env-shard x{world} + 1 grad all-reduce/minibatch"},
         "hip_graph": hip_graph, "hip_graphs_captured": int(last_metrics.get("hip_graphs_captured", 0)),

@@ -107,3 +107,150 @@ def test_two_rank_gloo():
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
         assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def _worker_buckets(rank, world, port, results):
+    """Two all-reduce buckets (the fused CLS tail's parameters first, all-reduced on their own and asynchronously, then the rest)
+    against the single bucket: the same gradients, bit for bit, in f32 and with the bf16 wire format."""
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, os.path.join(root, "2048-ppo-agent_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from src.ppo.ppo_agent import PPOAgent
+        from src.ppo.ppo_trainer import PPOTrainer
+        from src.ppo.rollout_buffer import RolloutBuffer
+
+        optim = dict(opt_name="adamw", max_lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,
+                     warmup_steps_ratio=0.1, scheduler_names=["constant", "constant"],
+                     blacklist_weight_modules=["norm", "embedding"])
+
+        def make(buckets):
+            os.environ["G2048_ALLREDUCE_BUCKETS"] = buckets
+            torch.manual_seed(3)
+            agent = PPOAgent(hidden_dim=512, d_model=256, nhead=8, num_layers=2, dim_feedforward=1024, dropout=0.0, reduction="cls")
+            tr = PPOTrainer(agent, None, RolloutBuffer(31, 16, 4), optim, max_steps=10, device=torch.device("cpu"),
+                            mixed_precision=None, use_action_mask=True)
+            return agent, tr
+
+        (a2, t2), (a1, t1) = make(""), make("1")  # default at world 2: two buckets; "1": the single one
+        early = a2.early_grad_parameters()
+        n_early = sum(p.numel() for p in early)
+        assert len(early) == 18 and t2._early_n == n_early and 0 < n_early < t2._flat_grad.numel()
+        assert t1._early_n == 0
+        # the early parameters lead the bucket, in one contiguous run
+        lead, off = {id(p) for p in t2._params[:18]}, 0
+        assert lead == {id(p) for p in early}
+        for p, v in zip(t2._params, t2._flat_views):
+            assert v.data_ptr() == t2._flat_grad.data_ptr() + 4 * off
+            off += p.numel()
+        g = torch.Generator().manual_seed(11 + rank)  # a different shard per rank
+        M = 6
+        boards = torch.randint(0, 10, (M, 16), generator=g, dtype=torch.uint8)
+        actions = torch.randint(0, 4, (M,), generator=g)
+        masks = torch.ones(M, 4, dtype=torch.bool)
+        old_lp, adv, ret = -torch.rand(M, generator=g), torch.randn(M, generator=g), torch.randn(M, generator=g)
+        for wire in (torch.float32, torch.bfloat16):
+            out = []
+            for agent, tr in ((a2, t2), (a1, t1)):
+                tr.allreduce_dtype = wire
+                agent.eval()
+                tr._zero_grad()
+                tr._compute_ppo_loss(boards, actions, masks, old_lp, adv, ret)[0].backward()
+                before = tr._early_launched
+                tr._early_armed = True  # what update_policy does around a minibatch
+                tr._allreduce_grads()
+                tr._early_armed = False
+                assert tr._early_launched - before == (1 if tr is t2 else 0) and tr._early_work is None
+                out.append({n: p.grad.clone() for n, p in agent.named_parameters()})
+            assert set(out[0]) == set(out[1])
+            for n in out[0]:
+                assert torch.equal(out[0][n], out[1][n]), (str(wire), n)
+            assert any(bool(v.abs().sum() > 0) for v in out[0].values())
+        # un-armed (a stray backward outside update_policy): one collective even with two buckets configured
+        t2._zero_grad()
+        t2._compute_ppo_loss(boards, actions, masks, old_lp, adv, ret)[0].backward()
+        before = t2._early_launched
+        t2._allreduce_grads()
+        assert t2._early_launched == before
+        results[rank] = "ok"
+    finally:
+        os.environ.pop("G2048_ALLREDUCE_BUCKETS", None)
+        dist.destroy_process_group()
+
+
+def test_two_bucket_allreduce_equals_one_bucket_bitwise():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_buckets, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def _worker_world8(rank, world, port, results):
+    """The 8-rank arithmetic of BASELINE configs[3] (524 288 boards over 8 GPUs) on CPU ranks: shard bounds, the per-rank share of
+    the reference's 300 000-sample subset, parameter broadcast, and the sharded gradient through the (two-bucket) all-reduce against
+    the single-process full-batch gradient.  (A world-8 rehearsal of bench.py itself would put 8 processes on the one GPU of the
+    test box, which its process guard forbids; test_gpu_dist.py rehearses bench.py with the ranks it allows.)"""
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, os.path.join(root, "2048-ppo-agent_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from src.ppo.ppo_agent import MLPAgent
+        from src.ppo.ppo_trainer import PPOTrainer
+        from src.ppo.rollout_buffer import RolloutBuffer
+
+        torch.manual_seed(100 + rank)
+        agent = MLPAgent(hidden_dim=16, trunk_dim=16)
+        optim = dict(opt_name="adamw", max_lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,
+                     warmup_steps_ratio=0.1, scheduler_names=["constant", "constant"],
+                     blacklist_weight_modules=["norm", "embedding"])
+        tr = PPOTrainer(agent, None, RolloutBuffer(31, 16, 4), optim, max_steps=10, device=torch.device("cpu"),
+                        mixed_precision=None, use_action_mask=True, max_samples_per_epoch=300000)
+        assert tr.world == 8 and tr.rank == rank
+        assert tr._shard(524288) == (65536, 65536 * rank, 524288)
+        assert tr._shard(1 << 20) == (131072, 131072 * rank, 1 << 20)
+        assert tr.per_rank_samples_per_epoch() == 37500  # 300 000 / 8: the number of optimiser steps per epoch does not grow with N
+        w0 = torch.cat([p.detach().flatten() for p in agent.parameters()])
+        gathered = [torch.zeros_like(w0) for _ in range(world)]
+        dist.all_gather(gathered, w0)
+        assert all(torch.equal(g, gathered[0]) for g in gathered), "parameters not broadcast"
+        g = torch.Generator().manual_seed(7)
+        M = 32
+        boards = torch.randint(0, 10, (M, 16), generator=g, dtype=torch.uint8)
+        actions = torch.randint(0, 4, (M,), generator=g)
+        masks = torch.ones(M, 4, dtype=torch.bool)
+        old_lp, adv, ret = -torch.rand(M, generator=g), torch.randn(M, generator=g), torch.randn(M, generator=g)
+        agent.eval()
+        ref = MLPAgent(hidden_dim=16, trunk_dim=16).eval()
+        ref.load_state_dict(agent.state_dict())
+        tr_ref = PPOTrainer.__new__(PPOTrainer)
+        tr_ref.agent, tr_ref.clip_epsilon, tr_ref.value_loss_coef, tr_ref.entropy_coef = ref, 0.2, 0.5, 0.01
+        tr_ref.use_action_mask = True
+        tr_ref._compute_ppo_loss(boards, actions, masks, old_lp, adv, ret)[0].backward()
+        want = torch.cat([p.grad.flatten() for p in ref.parameters()])
+        sl = slice(rank * M // world, (rank + 1) * M // world)
+        tr._zero_grad()
+        tr._compute_ppo_loss(boards[sl], actions[sl], masks[sl], old_lp[sl], adv[sl], ret[sl])[0].backward()
+        tr._early_armed = True
+        tr._allreduce_grads()
+        tr._early_armed = False
+        got = torch.cat([p.grad.flatten() for p in agent.parameters()])
+        np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-6, rtol=1e-5)
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_shards_budget_and_gradient():
+    world, port = 8, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_world8, args=(world, port, ret), nprocs=world, join=True)
+        assert dict(ret) == {r: "ok" for r in range(8)}

@@ -117,6 +117,20 @@ def _worker_default_shape(rank, world, port, results):
         tr._bind_flat_grads()
         rel = ((got - want).norm() / want.norm()).item()
         assert rel < 2e-3, rel
+        # (1b) the same minibatch eagerly, the way update_policy runs it without a graph: the fused CLS tail's parameters lead the
+        # bucket, their slice is summed by a launch of its own and its all-reduce starts from INSIDE the backward (GradSink.
+        # early_complete), the rest follows at the end -- the same gradient
+        assert 0 < tr._early_n < tr._flat_grad.numel() and len(tr._early_params) == 18
+        before = tr._early_launched
+        tr._zero_grad()
+        tr._armed_loss_backward({k: v.contiguous() for k, v in mine.items()})
+        assert tr._early_launched == before + 1 and tr._early_work is not None, "the early bucket did not start in the backward"
+        tr._allreduce_grads()
+        tr._early_armed = False
+        assert tr._early_work is None
+        got2 = torch.cat([v.flatten() for v in tr._flat_views])
+        rel2 = ((got2 - want).norm() / want.norm()).item()
+        assert rel2 < 2e-3, rel2
         # (2) a real update at this shape: graph replayed, parameters stay identical across ranks
         tr._graphs.clear()
         m = tr.update_policy(batch_size=1024, n_epochs=1)
@@ -148,18 +162,21 @@ def test_two_ranks_on_one_gpu(dev):
         assert r[0] == r[1] and r[0][0] > 0
 
 
-def test_bench_two_rank_dryrun_reaches_the_json_line(dev, tmp_path):
-    """bench.py --gpus 2 under G2048_BENCH_DRYRUN=1 (both ranks on this GPU, gloo): launched the way the driver launches it, it
-    must reach its JSON line with n_gpus 2 and the same number of optimiser steps on both ranks (rehearsal of the multi-GPU
-    control flow: sharding, the global sample budget, the gradient collective, the reductions of the extras)."""
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_two_rank_dryrun_reaches_the_json_line(dev, tmp_path, ranks):
+    """bench.py --gpus N under G2048_BENCH_DRYRUN=1 (all ranks on this GPU, gloo): launched the way the driver launches it, it
+    must reach its JSON line with n_gpus N and the same number of optimiser steps on all ranks (rehearsal of the multi-GPU
+    control flow: sharding, the global sample budget, the gradient collective, the reductions of the extras).  N = 4 is as far as
+    one box goes: its process guard allows 6 processes on the card, this one included (the 8-rank arithmetic itself -- shard
+    bounds, 300 000 / 8 samples per rank and epoch, the sharded gradient -- runs on CPU ranks in test_dist_gloo.py)."""
     import json
     import subprocess
     import sys
 
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     env = dict(os.environ, G2048_BENCH_DRYRUN="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "0",
            "--boards", "2048", "--train-batch", "512", "--epochs", "1", "--no-extras", "--no-cpu-baseline", "--roofline-boards",
            "65536"]
     p = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
@@ -167,6 +184,7 @@ def test_bench_two_rank_dryrun_reaches_the_json_line(dev, tmp_path):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and "DRYRUN" in out and out["config"]["global_boards"] == 4096
-    assert len(out["update_steps_per_rank"]) == 2 and len(set(out["update_steps_per_rank"])) == 1
+    assert out["n_gpus"] == ranks and "DRYRUN" in out and out["config"]["global_boards"] == 2048 * ranks
+    assert len(out["update_steps_per_rank"]) == ranks and len(set(out["update_steps_per_rank"])) == 1
+    assert out["config"]["max_samples_per_epoch_per_rank"] == 300000 // ranks
     assert out["update_minibatches_per_step"] >= 1 and out["value"] > 0 and out["allreduce"]["dtype"] == "float32"

@@ -345,3 +345,35 @@ def test_flat_step_leaves_parameters_without_gradient_alone(dev):
     torch.testing.assert_close(ps[0].detach(), ref[0].detach(), rtol=2e-6, atol=2e-6)
     torch.testing.assert_close(ps[2].detach(), ref[2].detach(), rtol=2e-6, atol=2e-6)
     assert torch.equal(ps[1].detach(), ref[1].detach()) and not bool(fs.m_views[1].any()) and not bool(fs.v_views[1].any())
+
+
+def test_graph_replayed_update_leaves_an_unused_parameter_alone(dev, tmp_path, monkeypatch):
+    """An agent with a parameter that no forward uses, through ``update_policy`` with the hipGraph on and off: the parameter and
+    its moments must stay untouched either way (torch.optim.AdamW skips ``p.grad is None``).  After a replay every ``p.grad``
+    points at a bucket slice, so the list of grad-less parameters has to come from the capture (``_GraphedFwdBwd.no_grad``);
+    recomputed from ``p.grad`` it was empty and the parameter was decayed by the graph path only."""
+    monkeypatch.chdir(tmp_path)
+
+    def run(graph):
+        torch.manual_seed(5)
+        agent = PPOAgent(hidden_dim=64, d_model=64, nhead=4, num_layers=2, dim_feedforward=128, dropout=0.0, reduction="cls")
+        agent.unused = nn.Parameter(torch.full((37, 5), 3.0))  # falls into the decay group: weight decay would shrink it
+        tr = _trainer(dev, agent, tmp_path / ("g" if graph else "e"), use_hip_graph=graph, rollout_amp=True)
+        assert tr._flat_step is not None
+        tr.collect_rollouts(batch_size=64, num_batches=1)
+        torch.manual_seed(6)
+        m = tr.update_policy(batch_size=256, n_epochs=2)
+        assert m["n_updates"] >= 4 and m["hip_graph"] == graph, m
+        return tr
+
+    for graph in (False, True):
+        tr = run(graph)
+        i = [k for k, p in enumerate(tr._params) if p is tr.agent.unused][0]
+        assert tr._no_grad == [i]
+        if graph:
+            assert all(g.no_grad == [i] for g in tr._graphs.values())
+        assert torch.equal(tr.agent.unused.detach(), torch.full((37, 5), 3.0, device=dev)), graph
+        fs = tr._flat_step
+        assert not bool(fs.m_views[i].any()) and not bool(fs.v_views[i].any())
+        # and the used parameters did move
+        assert float((tr.agent.actor[0].weight.detach() - 0).abs().sum()) > 0 and float(fs.m_views[0].abs().sum()) > 0
