@@ -135,6 +135,23 @@ __global__ void __launch_bounds__(kBlock) k_reset_fused(u32 s0, u32 s1, uint8_t 
     ep_len[i] = 0;
 }
 
+// *live_count += lanes of this workgroup that are still running; live_count NULL: nobody asked (the host polls every few
+// lock-steps only).  ONE atomic per workgroup, none for a workgroup without live lanes: adds to one address serialise at
+// ~12 ns each at the memory side, so one per WAVE (rounds 1-3) made the counter, not the arithmetic, the length of a launch
+// from ~2^20 boards on (757 us at 2^22 boards = 65 536 atomics).  (All lanes of the workgroup reach this call.)
+__device__ __forceinline__ void count_live(bool lane_live, u32 *live_count) {
+    if (!live_count) return;  // (uniform)
+    __shared__ u32 wave_live[kBlock / 64];
+    const unsigned long long b = __ballot(lane_live);
+    if ((threadIdx.x & 63) == 0) wave_live[threadIdx.x >> 6] = (u32)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 n = 0;
+        for (int w = 0; w < kBlock / 64; ++w) n += wave_live[w];
+        if (n) atomicAdd(live_count, n);
+    }
+}
+
 // Persistent multi-step rollout with a fused naive policy: the board lives in four VGPRs across all
 // n_steps; per live env-step the only HBM traffic is the trajectory write (16 B board + 1 B meta + 4 B
 // reward [+ 4 B log-prob]).
@@ -186,8 +203,7 @@ __global__ void __launch_bounds__(kBlock) k_rollout_fused(const StepKeyTable key
         done[i] = (uint8_t)d;
         ep_len[i] = (int32_t)len;
     }
-    const unsigned long long live = __ballot(in_range && d == 0);
-    if ((threadIdx.x & 63) == 0 && live) atomicAdd(live_count, (u32)__popcll(live));
+    count_live(in_range && d == 0, live_count);
 }
 
 // jax.random.fold_in(key, 0xFFFFFFFF): the per-step "reset" sub-key of the auto-reset mode, derived from the step
@@ -252,10 +268,7 @@ __global__ void __launch_bounds__(kBlock) k_policy_step(u32 as0, u32 as1, u32 ss
             }
         }
     }
-    if (!AUTO) {
-        const unsigned long long live = __ballot(in_range && d == 0);
-        if ((threadIdx.x & 63) == 0 && live) atomicAdd(live_count, (u32)__popcll(live));
-    }
+    if (!AUTO) count_live(in_range && d == 0, live_count);
 }
 
 // ---------------------------------------------------------------------------------------- GAE / buffer
@@ -497,7 +510,7 @@ static int policy_step_impl(int autoreset, uint32_t act_sub0, uint32_t act_sub1,
     if (!logits || !values || t < 0 || !boards || !masks || !ep_len || !tr_boards || !tr_meta || !tr_rewards || !tr_logp ||
         !tr_values || B <= 0 || env0 < 0 || B_total > kMaxEnvs || env0 + B > B_total || bad_mode(rng_mode))
         return G2048_EINVAL;
-    if (!autoreset && (!done || !live_count)) return G2048_EINVAL;
+    if (!autoreset && !done) return G2048_EINVAL;  // (live_count may be NULL: no poll after this lock-step)
     if (((uintptr_t)boards & 15) || ((uintptr_t)tr_boards & 15) || ((uintptr_t)logits & 15)) return G2048_EINVAL;
     const u32 bt = (u32)B_total, e0 = (u32)env0;
 #define G2048_PS(M, A)                                                                                                   \

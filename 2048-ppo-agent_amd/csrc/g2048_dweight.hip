@@ -53,7 +53,7 @@ __host__ __device__ constexpr int dw_nbuf(int bn) { return (160 * 1024) / (TOKS 
 template <int NTW, int WN>
 __device__ __forceinline__ void dweight_block(const __bf16 *__restrict__ dy, int64_t lddy, const __bf16 *__restrict__ x, int64_t ldx,
                                               __bf16 *__restrict__ parts, float *__restrict__ colsum, int64_t T, int N, int K, int slices,
-                                              int k_blocks, int block_id) {
+                                              int k_blocks, int block_id, bool parts_f32 = false) {
     constexpr int BN = 32 * NTW * WN, KTW = 2, NW = 2 * WN, THREADS = 64 * NW;
     constexpr int NBUF = dw_nbuf(BN), DIST = NBUF - 1;  // stage buffers; stages in flight ahead of the one being multiplied
     constexpr int ROWA = BN * 2, ROWB = BK * 2;            // LDS row bytes of the two tiles
@@ -171,6 +171,22 @@ __device__ __forceinline__ void dweight_block(const __bf16 *__restrict__ dy, int
     }
     // ---- epilogue: the block as bf16 through LDS (rows of 256 bytes), then full rows to parts[slice][n0 ..][k0 ..]
     lds_barrier();
+    if (parts_f32) {  // (uniform) f32 partials: the A/B switch of round 4 (G2048_DWEIGHT_PARTS=f32x8); [BN][128] f32 <= the stage buffers
+        float *const sm = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int a = 0; a < NTW; ++a)
+#pragma unroll
+            for (int b = 0; b < KTW; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sm[(32 * (NTW * wn + a) + rowof(i, h)) * BK + 32 * (KTW * wk + b) + r] = acc[a][b][i];
+        lds_barrier();
+        float *const out32 = reinterpret_cast<float *>(parts) + ((int64_t)slice * N + n0) * K + k0;
+        for (int e = tid; e < BN * (BK / 4); e += THREADS) {
+            const int nl = e / (BK / 4), c = e % (BK / 4);
+            *reinterpret_cast<uint4 *>(out32 + (int64_t)nl * K + 4 * c) = *reinterpret_cast<const uint4 *>(sm + nl * BK + 4 * c);
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < NTW; ++a)
 #pragma unroll
@@ -208,7 +224,7 @@ k_dweight_jobs(DwJobs J) {
     while (j + 1 < J.n_jobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;  // <= 16 entries, uniform
     const g2048_dwg_job &Q = J.job[j];
     dweight_block<1, 4>((const __bf16 *)Q.dy, Q.lddy, (const __bf16 *)Q.x, Q.ldx, (__bf16 *)Q.parts, Q.colsum, Q.T, Q.N, Q.K, Q.slices, Q.K / BK,
-                        (int)blockIdx.x - J.first_block[j]);
+                        (int)blockIdx.x - J.first_block[j], Q.parts_f32 != 0);
 }
 
 }  // namespace

@@ -2,8 +2,12 @@
 """Train a PPO agent on the MI355X engine -- the reference's run/train_ppo_agent.py:19-138 without Hydra.
 
     python run/train_ppo_agent.py [--config configs/train_ppo_agent.yaml] [key=value ...]
+    python run/train_ppo_agent.py --config /path/to/reference/configs/train_ppo_agent.yaml +experiment=resume_train_ppo_agent
     torchrun --nproc-per-node 8 run/train_ppo_agent.py trainer.rollout_batch_size=524288 trainer.rollout_batches=1
 
+``--config`` is either this repository's flattened file or the primary file of a Hydra-style config TREE -- the reference's own
+``configs/`` directory works unmodified: its ``defaults`` list (configs/train_ppo_agent.yaml:5-11) is composed by
+``run/config_tree.py`` (PyYAML only), with Hydra's command-line forms ``key.sub=value``, ``group=option``, ``+group=option``.
 Overrides use dotted keys (``trainer.total_timesteps=2000000 model.kind=mlp``).  Multi-GPU: one rank per GPU,
 ``rollout_batch_size`` is the global number of envs.  (The reference's own script also runs unmodified against this
 package when Hydra is installed: see INTEGRATION.md.)
@@ -13,8 +17,6 @@ import json
 import logging
 import os
 import sys
-
-import yaml
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
@@ -29,11 +31,13 @@ logging.basicConfig(level=logging.INFO)
 logger = logging.getLogger("train_ppo_agent")
 
 
-def _set(cfg, dotted, value):
-    keys = dotted.split(".")
-    for k in keys[:-1]:
-        cfg = cfg.setdefault(k, {})
-    cfg[keys[-1]] = yaml.safe_load(value)
+def load_config(path, overrides=()):
+    """Flattened file or config tree + command-line overrides -> dict (``config_tree.compose``)."""
+    if HERE not in sys.path:
+        sys.path.insert(0, HERE)
+    from config_tree import compose
+
+    return compose(path, overrides)
 
 
 def main():
@@ -42,10 +46,7 @@ def main():
     ap.add_argument("--eval-episodes", type=int, default=0, help="greedy masked evaluation after training")
     ap.add_argument("overrides", nargs="*")
     args = ap.parse_args()
-    cfg = yaml.safe_load(open(args.config))
-    for ov in args.overrides:
-        k, v = ov.split("=", 1)
-        _set(cfg, k, v)
+    cfg = load_config(args.config, args.overrides)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -53,7 +54,9 @@ def main():
     torch.cuda.set_device(device)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
-    seed = cfg.get("seed")
+    # the reference: cfg.get("seed", cfg.data.seed) (run/train_ppo_agent.py:40-42) -- its tree has a top-level `seed: null`, which
+    # OmegaConf returns as None: no torch seed and BatchRunner seed 0; `data.seed` only counts when the top-level key is absent
+    seed = cfg["seed"] if "seed" in cfg else (cfg.get("data") or {}).get("seed")
     if seed is not None:
         torch.manual_seed(seed)
     m = dict(cfg["model"])

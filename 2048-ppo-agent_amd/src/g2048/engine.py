@@ -257,11 +257,12 @@ class RolloutEngine:
                     logits_full.index_copy_(0, live_idx, lg.to(torch.float32))
                     values_full.index_copy_(0, live_idx, vl.to(torch.float32).reshape(-1))
                     logits, values = logits_full, values_full
-                if s == sync_every - 1:
+                poll = s == sync_every - 1  # only the launch the host reads back counts the live envs
+                if poll:
                     live.zero_()
                 nv.policy_step(subs[2 * s], subs[2 * s + 1], logits, values, use_mask, sample, t, boards, masks, done,
                                ep_len, bufs["boards"], bufs["meta"], bufs["rewards"], bufs["logp"], bufs["values"],
-                               B_total, env0, fill_frozen, self.rng_mode, live)
+                               B_total, env0, fill_frozen, self.rng_mode, live if poll else None)
                 t += 1
             n_live = int(live.item())
             if n_live == 0:

@@ -243,7 +243,7 @@ def policy_step(act_sub, step_sub, logits, values, use_mask, sample, t: int, boa
                                     _dev(tr_meta, u8, need, "tr_meta"), _dev(tr_rewards, f32, need, "tr_rewards"),
                                     _dev(tr_logp, f32, need, "tr_logp"), _dev(tr_values, f32, need, "tr_values"),
                                     B, B_total, env0, int(bool(fill_frozen)), rng_mode,
-                                    _dev(live_count, i32, 1, "live_count"), _stream()), "g2048_policy_step")
+                                    _dev(live_count, i32, 1, "live_count", optional=True), _stream()), "g2048_policy_step")
 
 
 def policy_step_autoreset(act_sub, step_sub, logits, values, use_mask, sample, t: int, boards, masks, ep_len, tr_boards,
@@ -791,7 +791,7 @@ def dweight_parts(dy2: torch.Tensor, x2: torch.Tensor, slices: int, out: torch.T
 
 class DwgJob(C.Structure):
     _fields_ = [("dy", _vp), ("x", _vp), ("parts", _vp), ("colsum", _vp), ("lddy", _i64), ("ldx", _i64), ("T", _i64),
-                ("N", _i32), ("K", _i32), ("slices", _i32), ("pad_", _i32)]
+                ("N", _i32), ("K", _i32), ("slices", _i32), ("parts_f32", _i32)]
 
 
 DWG_MAX_JOBS = 16
@@ -799,15 +799,18 @@ DWG_MAX_JOBS = 16
 
 def dweight_jobs(jobs):
     """Several ``dweight_parts`` products in one launch per ``DWG_MAX_JOBS`` (``g2048_dweight_jobs``).  jobs: (dy2, x2, parts bf16
-    [slices, N, K], colsum f32 [slices, N] or None); slices (= parts.shape[0]) a multiple of 8."""
+    (or f32: the job's ``parts_f32`` flag) [slices, N, K], colsum f32 [slices, N] or None); slices (= parts.shape[0]) a multiple of 8."""
     recs = []
     for dy2, x2, parts, cs in jobs:
         slices = parts.shape[0]
         if not dweight_ok(dy2, x2, slices) or slices % 8:
             raise NativeError(f"dweight_jobs: operands {tuple(dy2.shape)} x {tuple(x2.shape)} with {slices} slices are not supported")
         T, N, K = dy2.shape[0], dy2.shape[1], x2.shape[1]
-        recs.append(DwgJob(dy2.data_ptr(), x2.data_ptr(), _dev(parts, torch.bfloat16, slices * N * K, "parts"),
-                           None if cs is None else _dev(cs, f32, slices * N, "colsum"), dy2.stride(0), x2.stride(0), T, N, K, slices, 0))
+        if parts.dtype not in (torch.bfloat16, f32):
+            raise NativeError(f"dweight_jobs: parts must be bf16 or f32, got {parts.dtype}")
+        recs.append(DwgJob(dy2.data_ptr(), x2.data_ptr(), _dev(parts, parts.dtype, slices * N * K, "parts"),
+                           None if cs is None else _dev(cs, f32, slices * N, "colsum"), dy2.stride(0), x2.stride(0), T, N, K, slices,
+                           int(parts.dtype == f32)))
     for i in range(0, len(recs), DWG_MAX_JOBS):
         chunk = recs[i:i + DWG_MAX_JOBS]
         arr = (DwgJob * len(chunk))(*chunk)

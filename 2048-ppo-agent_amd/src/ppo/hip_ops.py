@@ -149,11 +149,12 @@ class GradSink:
         if self.on_early is not None:
             self.on_early()
 
-    def add_dweight(self, weight, bias, dy2: torch.Tensor, x2: torch.Tensor, slices: int, w_offset: int = 0, b_offset: int = 0):
+    def add_dweight(self, weight, bias, dy2: torch.Tensor, x2: torch.Tensor, slices: int, w_offset: int = 0, b_offset: int = 0,
+                    parts_dtype=torch.bfloat16):
         """dW = dy2^T x2 (and db = column sums of dy2) computed at ``flush`` together with every other deferred product; the partials
         are registered for the reduction now.  dy2 / x2 stay alive until then (~0.5 GB at minibatch 2048)."""
         N, K = dy2.shape[1], x2.shape[1]
-        parts = torch.empty((slices, N, K), dtype=torch.bfloat16, device=dy2.device)
+        parts = torch.empty((slices, N, K), dtype=parts_dtype, device=dy2.device)
         cs = torch.empty((slices, N), dtype=torch.float32, device=dy2.device) if bias is not None else None
         self.dw_jobs.append((dy2, x2, parts, cs))
         self.add(weight, parts, N * K, N * K, slices, w_offset)
@@ -302,11 +303,24 @@ def _deferred_dweight(sink, weight, bias, dy2, x2, w_offset: int = 0, b_offset: 
         return False
     from ..g2048 import native as nv
 
-    slices = 8
+    slices, dtype = _dweight_parts_config()
     if not nv.dweight_ok(dy2, x2, slices):
         return False
-    sink.add_dweight(weight, bias, dy2, x2, slices, w_offset, b_offset)
+    sink.add_dweight(weight, bias, dy2, x2, slices, w_offset, b_offset, parts_dtype=dtype)
     return True
+
+
+def _dweight_parts_config():
+    """(token slices, dtype of the partial products) of the deferred weight gradients.  Default 8 bf16 slices; G2048_DWEIGHT_PARTS =
+    bf16x16 / f32x8 are the other two arms of round 4's multi-seed A/B (profiles/round4_dweight_slices_seeds.txt), read per call so a
+    sweep can flip it between trainers of one process."""
+    import os
+
+    v = os.environ.get("G2048_DWEIGHT_PARTS", "bf16x8").strip().lower()
+    table = {"bf16x8": (8, torch.bfloat16), "bf16x16": (16, torch.bfloat16), "f32x8": (8, torch.float32), "f32x16": (16, torch.float32)}
+    if v not in table:
+        raise ValueError(f"G2048_DWEIGHT_PARTS must be one of {sorted(table)}, got {v!r}")
+    return table[v]
 
 
 def _sink_weight_bias(sink, weight, bias, dy2, x2, w_offset: int = 0, b_offset: int = 0):

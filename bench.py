@@ -48,8 +48,17 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling is ~6290 GB/s
 STEP_BYTES = 50  # board 16 r + 16 w, action 4, key 8, reward 4, mask 1, done 1
 POLICY_STEP_BYTES = 93  # fused policy step: state 18 r + 18 w (+ ep_len 4 r/w), logits 16, value 4, trajectory 29
+POLICY_STEP_VALU_PER_WAVE = 1150  # k_policy_step<partitionable, AUTO=0> (ISA count)
 STEP_VALU_PER_WAVE = 554  # vector instructions per wave of k_step<partitionable> (ISA count = SQ_INSTS_VALU / SQ_WAVES)
 VALU_PEAK_GINSTR = 1024 * 2.4 / 2  # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction on a SIMD-32 = 1228.8 G/s
+# What k_step's OWN instruction mix can issue: its 554 vector instructions by opcode (hipcc -save-temps) priced with the
+# per-opcode issue cost measured on this chip at 8 waves per SIMD (profiles/round1_valu_rate_microbench.txt: add / xor / and ~2.7-2.8
+# cycles per wave64 instruction, every three-operand, shift, permute or bit-field opcode 4.3-4.6):
+#   threefry x4: 80 alignbit x 4.52 + 78 xor x 2.72 + 95 add x 2.77 + 27 add3 x 4.59 + 20 xad x 4.56          = 1 052 cycles
+#   board logic: 46 bitop3 + 45 cndmask + 25 perm + 35 shifts + 10 bfe + 9 or3 at 4.3-4.6, 12 and at 2.7, ~72 others at ~3.5 = 1 044 cycles
+# = 2 096 cycles per wave = 3.78 cycles per instruction -> 1024 SIMDs x 2.4 GHz / 3.78 = 650 G wave-instructions/s.
+STEP_MIX_CYCLES_PER_INSTR = 2096.0 / 554.0
+VALU_MIX_PEAK_GINSTR = 1024 * 2.4 / STEP_MIX_CYCLES_PER_INSTR
 
 TRAINER_CFG = dict(gamma=0.99, lambda_gae=0.95, clip_epsilon=0.2, value_loss_coef=0.5, entropy_coef=0.01,
                    max_grad_norm=0.5, target_kl=0.25, use_action_mask=True, mixed_precision="bfloat16",
@@ -126,6 +135,13 @@ def step_kernel_roofline(dev, boards_per_launch: int, launches: int = 20):
         pass
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            # what actually binds this kernel: vector-ALU issue (PMC: SQ_WAIT_INST_ANY 72 % of wave cycles, HBM traffic = the
+            # algorithmic bytes); `binding_frac` = issued wave-instructions per second against what the kernel's own opcode mix
+            # can issue on 1024 SIMDs at 2.4 GHz (VALU_MIX_PEAK_GINSTR above; the chip holds ~2.1 GHz under this load)
+            "binding_bound": "valu", "binding_achieved": round(ginstr, 1), "binding_peak": round(VALU_MIX_PEAK_GINSTR, 1),
+            "binding_unit": "G wave-instr/s", "binding_frac": round(ginstr / VALU_MIX_PEAK_GINSTR, 4),
+            "binding_peak_source": "554 instructions per wave priced per opcode with profiles/round1_valu_rate_microbench.txt "
+                                   f"({STEP_MIX_CYCLES_PER_INSTR:.2f} cycles per instruction for this mix; bench.py header)",
             "kernel": "k_step (g2048_step)",
             "boards_per_launch": B, "launch_us": round(us, 2), "algorithmic_bytes_per_env_step": STEP_BYTES,
             "live_fraction": round(live, 3), **rng_floor,
@@ -149,22 +165,33 @@ def policy_step_saturated(dev, B: int = 1 << 22, launches: int = 10):
     stream = torch.cuda.current_stream()
     start, end = _events()
 
-    def launch():
+    def launch(counter):
         nv.policy_step((3, 4), (5, 6), logits, values, True, True, 0, boards, masks, done, ep, tr["b"], tr["m"], tr["r"], tr["l"],
-                       tr["v"], B, 0, True, nv.RNG_PARTITIONABLE, live)
+                       tr["v"], B, 0, True, nv.RNG_PARTITIONABLE, counter)
 
-    launch()
-    torch.cuda.synchronize()
-    start.record(stream)
-    for _ in range(launches):
-        launch()
-    end.record(stream)
-    torch.cuda.synchronize()
-    us = start.elapsed_time(end) * 1e3 / launches
+    def timed(counter):
+        launch(counter)
+        torch.cuda.synchronize()
+        start.record(stream)
+        for _ in range(launches):
+            launch(counter)
+        end.record(stream)
+        torch.cuda.synchronize()
+        return start.elapsed_time(end) * 1e3 / launches
+
+    us, us_counting = timed(None), timed(live)
     gbs = POLICY_STEP_BYTES * B / (us * 1e-6) / 1e9
+    ginstr = POLICY_STEP_VALU_PER_WAVE * (B / 64) / (us * 1e-6) / 1e9
     return {"kernel": "k_policy_step (g2048_policy_step)", "boards_per_launch": B, "launch_us": round(us, 2),
+            "launch_us_counting_live": round(us_counting, 2),
             "algorithmic_bytes_per_env_step": POLICY_STEP_BYTES, "achieved_GBps": round(gbs, 1),
-            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+            "binding_bound": "valu", "binding_achieved": round(ginstr, 1), "binding_peak": round(VALU_MIX_PEAK_GINSTR, 1),
+            "binding_unit": "G wave-instr/s", "binding_frac": round(ginstr / VALU_MIX_PEAK_GINSTR, 4),
+            "what": "launch_us: as 7 of 8 lock-steps of the rollout loop run it (no live counter); launch_us_counting_live: the "
+                    "launch the host polls, one atomic per workgroup with live lanes (rounds 1-3: one per wave to one address, "
+                    "which serialised at ~12 ns each and WAS the 757 us this object reported at 2^22 boards); ~1 150 vector "
+                    "instructions per wave (8 threefry blocks, 8 f32 logs, exp / log of the log-softmax), priced with k_step's mix"}
 
 
 def policy_encoder_roofline(agent, dev, boards: int, launches: int = 5):

@@ -104,7 +104,9 @@ int g2048_rollout_fused(const uint32_t *step_subs /*host*/, int n_steps, int64_t
 
 /* One lock-step with the policy's outputs already on the device: sample (or argmax) from logits,
  * log-prob, env step, trajectory write at step t -- the fusion of batch_runner.py:123-136 with
- * torch_action_wrapper.py:85-102.  logits f32[B][4], values f32[B] come from the agent forward. */
+ * torch_action_wrapper.py:85-102.  logits f32[B][4], values f32[B] come from the agent forward.
+ * live_count (device u32, zeroed by the caller; may be NULL when nobody polls after this step): += envs still running
+ * afterwards, one atomic per workgroup that has any. */
 int g2048_policy_step(uint32_t act_sub0, uint32_t act_sub1, uint32_t step_sub0, uint32_t step_sub1,
                       const float *logits, const float *values, int use_mask, int sample, int64_t t,
                       uint8_t *boards, uint8_t *masks, uint8_t *done, int32_t *ep_len, uint8_t *tr_boards,
@@ -290,12 +292,13 @@ int g2048_dweight_bf16(const void *dy, int64_t lddy, const void *x, int64_t ldx,
 
 /* The same for several Linears in ONE launch (the weight gradients of a whole backward pass, deferred to its end by the caller):
  * job j is g2048_dweight_bf16(dy, lddy, x, ldx, parts, colsum, T, N, K, slices, 128) with slices a multiple of 8.  jobs: host array,
- * read during the call. */
+ * read during the call.  parts_f32 != 0: the job's partials are stored as f32 [slices][N][K] instead of bf16 (twice the bytes into
+ * g2048_reduce_jobs; the switch behind profiles/round4_dweight_slices_seeds.txt). */
 #define G2048_DWG_MAX_JOBS 16
 typedef struct {
     const void *dy; const void *x; void *parts; float *colsum;
     int64_t lddy, ldx, T;
-    int32_t N, K, slices, pad_;
+    int32_t N, K, slices, parts_f32;
 } g2048_dwg_job;
 int g2048_dweight_jobs(const g2048_dwg_job *jobs, int n_jobs, void *stream);
 

@@ -1094,6 +1094,13 @@ def test_dweight_parts_match_f32_reference(dev):
         assert torch.equal(parts, want[0] if cs is not None else want)
         if cs is not None:
             assert torch.equal(cs, want[1])
+    # f32 partials (the job's parts_f32 flag; round 4's A/B arm G2048_DWEIGHT_PARTS=f32x8): the same accumulators, stored unrounded
+    dy, x, parts16, _ = jobs[0]
+    S = 8
+    p32, p16 = torch.empty(S, 1024, 256, dtype=torch.float32, device=dev), torch.empty(S, 1024, 256, dtype=torch.bfloat16, device=dev)
+    nv.dweight_jobs([(dy, x, p32, None), (dy, x, p16, None)])
+    assert torch.equal(p32.to(torch.bfloat16), p16), "bf16 partials must be the rounding of the f32 ones"
+    assert rel(p32.sum(0), dy.float().t() @ x.float()) < 1e-5
     # views: column slices of wider activations (leading dimension != width)
     wide_dy = (torch.randn(2048, 768, device=dev) / 8).to(torch.bfloat16)
     wide_x = torch.randn(2048, 512, device=dev).to(torch.bfloat16)

@@ -135,6 +135,31 @@ def _fp32_reference_grads(agent, tr, sample):
     return [p.grad.clone() for p in ref.parameters()], loss.item()
 
 
+def _autocast_reference_grads(agent, tr, sample):
+    """The yardstick: the reference loss back-propagated through PLAIN PyTorch modules under bf16 autocast (one-hot Linear,
+    nn.TransformerEncoder, the heads; no kernel of this repository) on a copy of the weights -- what the reference's own update
+    computes for this minibatch.  Its distance to the fp32 backward is what bf16 costs on THIS batch."""
+    from torch.distributions import Categorical
+
+    ref = copy.deepcopy(agent).float().train()
+    ref.transformer._shadow = None
+    ref._head_shadow = None
+    masks = (sample["masks"].unsqueeze(-1) & torch.tensor(BITS, dtype=torch.uint8, device=sample["masks"].device)) != 0
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits, values = _torch_forward(ref, sample["obs"], "cls")
+        if tr.use_action_mask:
+            logits = logits - 1e8 * (1 - masks.float())
+        dist = Categorical(logits=logits, validate_args=False)
+        new_lp, entropy = dist.log_prob(sample["actions"].long()), dist.entropy()
+        ratio = torch.exp(new_lp - sample["old_lp"])
+        adv = sample["adv"]
+        policy_loss = -torch.min(ratio * adv, torch.clamp(ratio, 1 - tr.clip_epsilon, 1 + tr.clip_epsilon) * adv)
+        value_loss = torch.nn.functional.mse_loss(values.flatten(), sample["ret"], reduction="none")
+        loss = (policy_loss + tr.value_loss_coef * value_loss - tr.entropy_coef * entropy).mean()
+    loss.backward()
+    return [p.grad.float().clone() for p in ref.parameters()]
+
+
 def test_hip_graph_update_at_bench_shape_matches_fp32_backward(dev, tmp_path):
     """The shape bench.py runs (4 layers, ff 1024, minibatch 2048; dropout forced to 0 so every path is deterministic):
     eager HIP-path gradients AND hipGraph-replayed gradients, on batches other than the captured one, against a
@@ -159,24 +184,32 @@ def test_hip_graph_update_at_bench_shape_matches_fp32_backward(dev, tmp_path):
     want = [_fp32_reference_grads(agent, tr, s) for s in samples]
     names = [n for n, _ in agent.named_parameters()]
 
-    # The bf16 noise of a minibatch gradient is a sum of 2048 per-board rounding errors and does not shrink when the boards'
-    # contributions cancel, while the gradient itself does (z-scored returns: its size follows the batch mean of R).  Measured
-    # with this seed (tools/debug_benchshape_rows.py): |g_hip - g32| = 0.0138 / 0.0174 / 0.0203 for |g32| = 0.307 / 0.419 / 0.181,
-    # forward errors identical in all three batches (values 5e-4 rms, logits 1.2e-3).  The error is therefore bounded against the
-    # mean gradient norm of the three batches, and the direction per batch.
-    g_scale = sum(torch.cat([g.flatten() for g in w[0]]).norm().item() for w in want) / len(want)
+    # PER BATCH (round 4; round 3 had bounded the error against the mean gradient norm of the three batches, behind which a bad
+    # batch could hide): the bf16 noise of a minibatch gradient is a sum of 2048 per-board rounding errors and does not shrink when
+    # the boards' contributions cancel, while the gradient itself does (z-scored returns: its size follows the batch mean of R;
+    # tools/debug_benchshape_rows.py: |g_hip - g32| = 0.0138 / 0.0174 / 0.0203 for |g32| = 0.307 / 0.419 / 0.181).  So the yardstick
+    # for batch i is what PyTorch's OWN bf16 autocast backward loses on batch i (`_autocast_reference_grads`): the HIP path may be
+    # 1.3 x that + 1 % of the batch's gradient norm, as a whole and per parameter tensor, and its direction no worse than
+    # autocast's by more than 0.003 in cosine.
+    yard = [_autocast_reference_grads(agent, tr, smp) for smp in samples]
+    flat = lambda gs: torch.cat([g.flatten() for g in gs])
+    report = []
 
     def check(tag, i):
         flat_g = torch.cat([(p.grad / scale).flatten() for p in agent.parameters()])
-        flat_w = torch.cat([g.flatten() for g in want[i][0]])
+        flat_w, flat_y = flat(want[i][0]), flat(yard[i])
         assert torch.isfinite(flat_g).all(), tag
         cos = torch.nn.functional.cosine_similarity(flat_g, flat_w, dim=0).item()
-        err = (flat_g - flat_w).norm().item()
-        assert err < 0.1 * g_scale and cos > 0.99, (tag, i, cos, err, g_scale)
-        for n, p, gw in zip(names, agent.parameters(), want[i][0]):
-            # per tensor: bf16 noise relative to the tensor's own gradient norm, floor for near-zero gradients
-            err = ((p.grad / scale - gw).norm() / (gw.norm() + 1e-3 * flat_w.norm())).item()
-            assert err < 0.25, (tag, i, n, err)
+        cos_y = torch.nn.functional.cosine_similarity(flat_y, flat_w, dim=0).item()
+        err, err_y, gn = (flat_g - flat_w).norm().item(), (flat_y - flat_w).norm().item(), flat_w.norm().item()
+        report.append((tag, i, round(err / gn, 4), round(err_y / gn, 4), round(cos, 5), round(cos_y, 5)))
+        assert err < 1.3 * err_y + 0.01 * gn and cos > cos_y - 0.003, (tag, i, cos, cos_y, err, err_y, gn)
+        bad = {}
+        for n, p, gw, gy in zip(names, agent.parameters(), want[i][0], yard[i]):
+            e_hip, e_y = (p.grad / scale - gw).norm().item(), (gy - gw).norm().item()
+            if not e_hip < 1.3 * e_y + 0.01 * gw.norm().item() + 1e-3 * gn:  # (floor for tensors with a near-zero gradient)
+                bad[n] = (round(e_hip / gn, 5), round(e_y / gn, 5))
+        assert not bad, (tag, i, bad)
 
     for i, s in enumerate(samples):  # eager HIP path
         stats, _ = tr._loss_backward(**s)
@@ -187,6 +220,7 @@ def test_hip_graph_update_at_bench_shape_matches_fp32_backward(dev, tmp_path):
         stats, _ = gr.run(samples[i])
         assert abs(stats[3].item() - want[i][1]) < 0.02 * max(1.0, abs(want[i][1]))
         check("graph", i)
+    print("bench-shape gradient check (tag, batch, |g_hip - g32| / |g32|, |g_autocast - g32| / |g32|, cos hip, cos autocast):", report)
 
 
 def test_update_policy_replays_a_graph_at_bench_shape(dev, tmp_path):

@@ -373,3 +373,75 @@ def test_fixed_horizon_per_episode_reward_statistic():
         vals, carry = traj.finished_episode_max_rewards(carry)
         assert vals.tolist() == want and vals.numel() == traj.finished_episode_lengths().numel()
         assert carry.tolist() == run
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config trees (run/config_tree.py): the reference's Hydra layout through PyYAML
+# ---------------------------------------------------------------------------------------------------------------------
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2048-ppo-agent_amd")
+
+
+def _config_tree():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("config_tree", os.path.join(PKG, "run", "config_tree.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_config_tree_composes_defaults_overrides_and_interpolations(tmp_path):
+    """A synthetic tree with every form the loader promises: defaults order with _self_ first (groups override the primary file),
+    a `# @package _global_` group merged at the root, group re-selection, +group, dotted overrides, ~delete, ${...} interpolation,
+    exponent floats without a dot (PyYAML reads `4e-4` as a string)."""
+    ct = _config_tree()
+    w = lambda rel, text: (os.makedirs(os.path.dirname(tmp_path / rel), exist_ok=True), open(tmp_path / rel, "w").write(text))
+    w("main.yaml", "defaults:\n  - _self_\n  - model: small\n  - trainer: default\n  - paths: default\n\ntask_name: t\nseed: null\n"
+                   "trainer:\n  gamma: 0.5\n")
+    w("model/small.yaml", "d_model: 64\nnhead: 4\n")
+    w("model/big.yaml", "d_model: 256\nnhead: 8\n")
+    w("trainer/default.yaml", "gamma: 0.99\noptim:\n  max_lr: 4e-4\n  eps: 1e-6\n  betas:\n    - 0.9\n    - 0.999\nresume_from_checkpoint: null\n")
+    w("paths/default.yaml", "work_dir: ${hydra:runtime.cwd}\nmodels_dir: ${paths.work_dir}/../.models\n")
+    w("experiment/resume.yaml", "# @package _global_\n\ntask_name: resumed\ntrainer:\n  optim:\n    max_lr: 1e-5\n"
+                                "  resume_from_checkpoint: ${paths.models_dir}/best.pt\n")
+    c = ct.compose(str(tmp_path / "main.yaml"))
+    assert c["model"] == {"d_model": 64, "nhead": 4} and c["seed"] is None and c["task_name"] == "t"
+    assert c["trainer"]["gamma"] == 0.99, "_self_ comes first: the trainer group overrides the primary file's value"
+    assert c["trainer"]["optim"] == {"max_lr": 4e-4, "eps": 1e-6, "betas": [0.9, 0.999]}
+    assert c["paths"]["work_dir"] == os.getcwd() and c["paths"]["models_dir"] == os.getcwd() + "/../.models"
+    c = ct.compose(str(tmp_path / "main.yaml"), ["model=big", "+experiment=resume", "trainer.gamma=0.9", "trainer.optim.eps=1e-8",
+                                                 "extra.deep.key=[1, 2]", "~task_name"])
+    assert c["model"]["d_model"] == 256 and c["trainer"]["gamma"] == 0.9 and c["trainer"]["optim"]["max_lr"] == 1e-5
+    assert c["trainer"]["optim"]["eps"] == 1e-8 and c["trainer"]["optim"]["betas"] == [0.9, 0.999]
+    assert c["trainer"]["resume_from_checkpoint"] == os.getcwd() + "/../.models/best.pt"
+    assert c["extra"]["deep"]["key"] == [1, 2] and "task_name" not in c and "experiment" not in c
+    with pytest.raises(FileNotFoundError):
+        ct.compose(str(tmp_path / "main.yaml"), ["model=missing"])
+    # a file without a defaults list (this repository's flattened config) passes through, overrides applied
+    flat = ct.compose(os.path.join(PKG, "configs", "train_ppo_agent.yaml"), ["trainer.rollout_batch_size=64", "model.kind=mlp"])
+    assert flat["trainer"]["rollout_batch_size"] == 64 and flat["model"]["kind"] == "mlp" and flat["trainer"]["optim"]["max_lr"] == 4e-4
+
+
+def test_reference_config_tree_loads_unmodified():
+    """The reference's own configs/ directory (configs/train_ppo_agent.yaml:5-17) through the loader: the composed values are the
+    ones this repository's flattened file states, and they build the default agent and the trainer's argument set."""
+    ref = "/root/reference/configs/train_ppo_agent.yaml"
+    if not os.path.exists(ref):
+        pytest.skip("the reference tree is only present in the build container")
+    ct = _config_tree()
+    c = ct.compose(ref)
+    flat = ct.compose(os.path.join(PKG, "configs", "train_ppo_agent.yaml"))
+    assert c["seed"] is None and c["data"]["seed"] == 42 and c["task_name"] == "train_transformer_combined"
+    assert c["model"] == {k: v for k, v in flat["model"].items() if k != "kind"}
+    assert c["trainer"] == flat["trainer"]
+    assert isinstance(c["trainer"]["optim"]["max_lr"], float) and isinstance(c["trainer"]["optim"]["eps"], float)
+    assert "hydra" in c and "paths" in c
+    r = ct.compose(ref, ["+experiment=resume_train_ppo_agent", "trainer.rollout_batch_size=65536"])
+    assert r["trainer"]["entropy_coef"] == 0.0001 and r["trainer"]["optim"]["max_lr"] == 1e-5 and r["trainer"]["optim"]["eps"] == 1e-6
+    assert r["trainer"]["resume_from_checkpoint"].endswith("/.models/current_best.pt") and "${" not in r["trainer"]["resume_from_checkpoint"]
+    assert r["trainer"]["rollout_batch_size"] == 65536 and r["task_name"] == "resume_train_transformer_combined"
+    from src.ppo import PPOAgent
+
+    m = dict(c["model"])
+    m.pop("observation_length")
+    assert sum(p.numel() for p in PPOAgent(**m).parameters()) == 3958272
