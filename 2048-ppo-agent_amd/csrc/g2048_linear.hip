@@ -184,7 +184,7 @@ k_linear(const __bf16 *__restrict__ x, int64_t ldx, const __bf16 *__restrict__ w
 // Round 2's kernel kept the weight slice in LDS and let every lane walk its own token row in global memory (the B operand: 16 bytes
 // per lane and k-step).  A wave-instruction of that kind is 64 separate 16-byte requests (lane = row); rocprofv3 showed the waves
 // stalled at instruction issue for 58 % of their cycles (SQ_WAIT_INST_ANY) at 2.0-2.4 TB/s, and neither the instruction order nor the
-// store pattern moved it.  Here the roles are swapped:
+// store pattern moved it (NOTES.md 3).  Here the roles are swapped:
 //   * the waves of a workgroup (8, or 4 for widths that are not multiples of 256) split the slice's OUTPUT features, one 32-row weight
 //     tile each: a wave's whole weight tile over K <= 256 is 16 fragments = 64 registers, loaded once per workgroup from nn.Linear's
 //     row-major layout;

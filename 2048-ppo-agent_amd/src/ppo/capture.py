@@ -2,7 +2,7 @@
 MLP policy's rollout forward in ``torch_action_wrapper.TorchActionFunction._graphed``).
 
 Why a guard: Python's cyclic garbage collector may run at ANY allocation, also in the middle of a stream capture.  If that
-collection finalises device objects of earlier work -- in the recorded case ("The 10:48 abort") a previous
+collection finalises device objects of earlier work -- in the recorded case (NOTES.md 3, "The 10:48 abort") a previous
 ``PPOTrainer`` kept alive only by reference cycles, i.e. its ``_GraphedFwdBwd`` objects: ``torch.cuda.CUDAGraph`` instances
 with their private allocator pools and the static input / gradient tensors allocated from those pools -- then the C++
 destructors run on the capturing thread: ``CUDAGraph::~CUDAGraph`` destroys the graph / graph-exec handles and releases the

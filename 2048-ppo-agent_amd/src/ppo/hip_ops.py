@@ -20,7 +20,7 @@ class Bf16Shadow:
 
     _live = weakref.WeakSet()
 
-    def __init__(self, params, transposed=(), packed=()):
+    def __init__(self, params, transposed=(), packed=(), packed_only=(), packed_t_only=()):
         self.params = list(params)
         self.key, self.flat, self.views = None, None, None
         self.transposed = tuple(transposed)  # indices of 2-D params that also get a [in, out] copy (``tviews[i]``)
@@ -28,6 +28,9 @@ class Bf16Shadow:
         # indices of 2-D params that also get fragment-packed copies of the tensor and of its transpose (``pviews[i]``,
         # ``ptviews[i]``: flat bf16 tensors in the MFMA operand order of include/g2048.h, read by the fused CLS tail kernels)
         self.packed = tuple(packed)
+        # the same, one orientation only: ``packed_only`` the tensor itself (forward operand of g2048_linear_add_ln_fwd),
+        # ``packed_t_only`` its transpose (operand of the fused input-gradient GEMM, g2048_linear_add_ln_bwd)
+        self.packed_only, self.packed_t_only = tuple(packed_only), tuple(packed_t_only)
         self.pviews, self.ptviews = {}, {}
         # set by an optimiser that rewrites the shadow together with the parameters (optim.flat_step.FlatAdamWStep): the
         # shadow then copies only when its key is stale (someone else changed a parameter), also during a hipGraph capture
@@ -37,10 +40,12 @@ class Bf16Shadow:
     def __getstate__(self):
         """copy.deepcopy / pickle of an agent: the copy starts cold - no buffers and no maintainer (both belong to the
         original's optimiser, which must not travel with a pickled module) - and registers itself like a new shadow."""
-        return {"params": self.params, "transposed": self.transposed, "packed": self.packed}
+        return {"params": self.params, "transposed": self.transposed, "packed": self.packed, "packed_only": self.packed_only,
+                "packed_t_only": self.packed_t_only}
 
     def __setstate__(self, state):
-        self.__init__(state["params"], state["transposed"], state.get("packed", ()))
+        self.__init__(state["params"], state["transposed"], state.get("packed", ()), state.get("packed_only", ()),
+                      state.get("packed_t_only", ()))
 
     def invalidate(self):
         self.key = None
@@ -79,17 +84,20 @@ class Bf16Shadow:
                 self.views = [self.flat[o:o + q.numel()].view(q.shape) for o, q in zip(offs, ps)]
                 self.tviews = {i: torch.empty(ps[i].shape[::-1], dtype=torch.bfloat16, device=ps[0].device)
                                for i in self.transposed}
-                self.pviews = {i: torch.empty(ps[i].numel(), dtype=torch.bfloat16, device=ps[0].device) for i in self.packed}
-                self.ptviews = {i: torch.empty(ps[i].numel(), dtype=torch.bfloat16, device=ps[0].device) for i in self.packed}
+                self.pviews = {i: torch.empty(ps[i].numel(), dtype=torch.bfloat16, device=ps[0].device)
+                               for i in self.packed + self.packed_only}
+                self.ptviews = {i: torch.empty(ps[i].numel(), dtype=torch.bfloat16, device=ps[0].device)
+                                for i in self.packed + self.packed_t_only}
             with torch.no_grad():
                 torch._foreach_copy_(self.views, [q.detach() for q in ps])
                 for i, tv in self.tviews.items():
                     tv.copy_(self.views[i].t())
-                if self.pviews:
+                if self.pviews or self.ptviews:
                     from ..g2048 import native as nv
 
-                    for i in self.packed:
+                    for i in self.pviews:
                         self.pviews[i].copy_(nv.pack_fragments(self.views[i]))
+                    for i in self.ptviews:
                         self.ptviews[i].copy_(nv.pack_fragments(self.views[i].t()))
             # a copy recorded into a hipGraph has not run yet: leave the key stale so that the next eager use copies for real
             self.key = None if (ps[0].is_cuda and torch.cuda.is_current_stream_capturing()) else key
@@ -213,7 +221,7 @@ def _colsum(t: torch.Tensor, out=None) -> torch.Tensor:
 
         return nv.colsum(t, out)
     if t.is_cuda and torch.cuda.is_current_stream_capturing():
-        # at::sum's cross-workgroup stage yields wrong values when replayed from a hipGraph on this stack:
+        # at::sum's cross-workgroup stage yields wrong values when replayed from a hipGraph on this stack (NOTES.md 3):
         # refuse to capture it, PPOTrainer._build_graph then falls back to the eager update
         raise RuntimeError(f"column sum of a {tuple(t.shape)} {t.dtype} tensor (strides {t.stride()}) is outside "
                            "g2048_colsum's shapes and at::sum must not be captured in a hipGraph")
@@ -256,6 +264,39 @@ def _stationary_ok(x2: torch.Tensor, wb: torch.Tensor) -> bool:
     from ..g2048 import native as nv
 
     return nv.linear_ok(x2, wb)
+
+
+def _rowgemm_on() -> bool:
+    """G2048_ROWGEMM=0 switches the fused Linear + add + LayerNorm launches (g2048_linear_add_ln_fwd / _bwd) off: the A/B switch."""
+    import os
+
+    return os.environ.get("G2048_ROWGEMM", "1").strip().lower() not in ("0", "false", "no", "off")
+
+
+class HLink:
+    """Joins the node that PRODUCES a normalised activation h (``_AddLayerNorm`` / ``_LinearAddLayerNorm``) with the Linear that consumes
+    it (in_proj: ``_LinearSplitK``, linear1: ``_LinearReluDropout``): in the backward the consumer does not run its input-gradient GEMM
+    but leaves its operands here (``pending`` = (dy [T, K] bf16, fragment-packed transpose of its weight)) and returns no gradient for
+    h; the producer's backward then runs GEMM and LayerNorm backward as ONE launch (``g2048_linear_add_ln_bwd``): the bf16 [T, 256]
+    gradient between them never exists.  ``armed``: set by the producer's forward when its backward can do that."""
+
+    __slots__ = ("armed", "pending")
+
+    def __init__(self):
+        self.armed, self.pending = False, None
+
+    def offer(self, dy2: torch.Tensor, wt_packed) -> bool:
+        """Called by the consumer's backward: True if the producer will compute the input gradient itself."""
+        from ..g2048 import native as nv
+
+        if not self.armed or wt_packed is None or self.pending is not None or not _rowgemm_on() or not nv.rowgemm_ok(dy2, wt_packed):
+            return False
+        self.pending = (dy2, wt_packed)
+        return True
+
+    def take(self):
+        p, self.pending = self.pending, None
+        return p
 
 
 class FFNLink:
@@ -378,7 +419,8 @@ class _LinearSplitK(torch.autograd.Function):
     SLICES = 16
 
     @staticmethod
-    def forward(ctx, x, weight, bias, wb=None, bb=None):
+    def forward(ctx, x, weight, bias, wb=None, bb=None, h_link=None, wt_packed=None):
+        ctx.h_link, ctx.wt_packed = h_link, wt_packed  # (HLink: the producer of x may run this node's input-gradient GEMM itself)
         with torch.autocast("cuda", enabled=False):
             xb = x.to(torch.bfloat16)
             if wb is None:
@@ -404,15 +446,17 @@ class _LinearSplitK(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16)
             x2 = xb.reshape(-1, xb.shape[-1])
-            dx = (dy2 @ wb).view(xb.shape).to(x_dtype) if ctx.needs_input_grad[0] else None
+            dx = None
+            if ctx.needs_input_grad[0] and not (ctx.h_link is not None and ctx.h_link.offer(dy2.contiguous(), ctx.wt_packed)):
+                dx = (dy2 @ wb).view(xb.shape).to(x_dtype)
             weight, bias = ctx.params
             sink = _sink_for(weight, bias) if w_dtype == torch.float32 and b_dtype in (None, torch.float32) else None
             if sink is not None:
                 _sink_weight_bias(sink, weight, bias, dy2, x2)
-                return dx, None, None, None, None
+                return dx, None, None, None, None, None, None
             dw = _dweight(dy2, x2).to(w_dtype)
             db = None if b_dtype is None else _colsum(dy2).to(b_dtype)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _LinearRelu(torch.autograd.Function):
@@ -462,7 +506,7 @@ class _InProjCls(torch.autograd.Function):
     the gradients of the whole in_proj weight and bias assembled in one buffer (slicing the parameter instead costs a
     zero-fill, a copy and an accumulate per slice in the backward).  h, wb, bb bf16; weight/bias the f32 masters.
     The CLS rows are first gathered into a contiguous [B, D] matrix (one 1 MB copy at minibatch 2048), so that no GEMM
-    of the update takes the [B, 1, D] view with row stride 17 * D as an operand ("the 02:59 fault")."""
+    of the update takes the [B, 1, D] view with row stride 17 * D as an operand (NOTES.md 3, "the 02:59 fault")."""
 
     @staticmethod
     def forward(ctx, h, weight, bias, wb, bb):
@@ -616,10 +660,13 @@ class _AddLayerNorm(torch.autograd.Function):
     x f32 [..., 256] (a [B, 1, 256] slice of the residual stream is read in place), a bf16; returns (x_new, h)."""
 
     @staticmethod
-    def forward(ctx, x, a, gamma, beta, eps, p_drop):
+    def forward(ctx, x, a, gamma, beta, eps, p_drop, h_link=None):
         from ..g2048 import native as nv
 
         ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None, not as a zero-filled tensor
+        ctx.h_link = h_link
+        if h_link is not None:
+            h_link.armed = _rowgemm_on()
         x, row_stride = _residual_rows(x)
         T = x.numel() // 256
         gamma, beta = gamma.contiguous(), beta.contiguous()
@@ -652,18 +699,25 @@ class _AddLayerNorm(torch.autograd.Function):
         T = xn.numel() // 256
         dx = torch.empty(xn.shape, dtype=torch.float32, device=xn.device)
         da = torch.empty(xn.shape, dtype=torch.bfloat16, device=xn.device) if has_a else None
-        if g_h is None:
-            g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
         g_x = g_x.contiguous() if g_x is not None else None
         sink = _sink_for(*ctx.params)
-        dparams = None if sink is not None else torch.empty((3, 256), dtype=torch.float32, device=xn.device)
-        ws = nv.add_ln_bwd(xn.data_ptr(), row_stride, g_x, g_h.contiguous(), stats[0], stats[1], gamma, dx, da, dparams, T, p_drop,
-                           *seed)
+        pend = ctx.h_link.take() if ctx.h_link is not None else None
+        if pend is not None:  # the consumer of h left its input-gradient GEMM to this node: GEMM + LayerNorm backward in one launch
+            if g_h is not None:
+                raise RuntimeError("the normalised activation has a second consumer besides the linked Linear")
+            ws = nv.linear_add_ln_bwd(pend[0], pend[1], xn.data_ptr(), row_stride, g_x, stats[0], stats[1], gamma, dx, da, p_drop, *seed)
+            dparams = None if sink is not None else ws.sum(0).view(3, 256)
+        else:
+            if g_h is None:
+                g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
+            dparams = None if sink is not None else torch.empty((3, 256), dtype=torch.float32, device=xn.device)
+            ws = nv.add_ln_bwd(xn.data_ptr(), row_stride, g_x, g_h.contiguous(), stats[0], stats[1], gamma, dx, da, dparams, T, p_drop,
+                               *seed)
         if sink is not None:
             sink.add(ctx.params[0], ws, 768, 256, ws.shape[0])
             sink.add(ctx.params[1], ws[:, 256:], 768, 256, ws.shape[0])
-            return dx, da, None, None, None, None
-        return dx, da, dparams[0], dparams[1], None, None
+            return dx, da, None, None, None, None, None
+        return dx, da, dparams[0], dparams[1], None, None, None
 
 
 def _residual_rows(x: torch.Tensor):
@@ -710,16 +764,17 @@ class _LinearAddLayerNorm(torch.autograd.Function):
     masters weight/bias, x f32; returns (x_new, h)."""
 
     @staticmethod
-    def forward(ctx, u, weight, bias, wb, bb, x, gamma, beta, eps, p_drop, wbT=None, link=None, cls_link=None):
+    def forward(ctx, u, weight, bias, wb, bb, x, gamma, beta, eps, p_drop, wbT=None, link=None, cls_link=None, h_link=None,
+                w_packed=None):
         from ..g2048 import native as nv
 
         ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None, not as a zero-filled tensor
-        with torch.autocast("cuda", enabled=False):
-            a = _hip_linear(u.reshape(-1, u.shape[-1]), wb, bias.detach()) if bias is not None and u.is_contiguous() else None
-            a = F.linear(u, wb, bb) if a is None else a.view(*u.shape[:-1], wb.shape[0])
         ctx.wbT, ctx.link = wbT, link
         ctx.params = (weight, bias, gamma, beta)
         ctx.cls_link = cls_link
+        ctx.h_link = h_link
+        if h_link is not None:
+            h_link.armed = _rowgemm_on()
         if cls_link is not None:
             cls_link.attached = x.dim() == 3  # [B, S, 256]: the period of the CLS rows is S
         x, row_stride = _residual_rows(x)
@@ -729,7 +784,17 @@ class _LinearAddLayerNorm(torch.autograd.Function):
         x_new = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         stats = torch.empty((2, T), dtype=torch.float32, device=x.device)
         seed = _seed_pair(x, p_drop)
-        nv.add_ln_fwd(x.data_ptr(), row_stride, a, gamma, beta, x_new, h, stats[0], stats[1], T, eps, p_drop, *seed)
+        u2 = u.reshape(-1, u.shape[-1])
+        if (w_packed is not None and _rowgemm_on() and u2.shape[0] == T and T >= 4096 and (bias is None or bias.dtype == torch.float32)
+                and nv.rowgemm_ok(u2, w_packed)):
+            # the Linear, dropout, the residual add and the LayerNorm in one launch: the Linear's bf16 output stays in LDS
+            nv.linear_add_ln_fwd(u2, w_packed, None if bias is None else bias.detach(), x.data_ptr(), row_stride, gamma, beta, x_new, h,
+                                 stats[0], stats[1], eps, p_drop, *seed)
+        else:
+            with torch.autocast("cuda", enabled=False):
+                a = _hip_linear(u2, wb, bias.detach()) if bias is not None and u.is_contiguous() else None
+                a = F.linear(u, wb, bb) if a is None else a.view(*u.shape[:-1], wb.shape[0])
+            nv.add_ln_fwd(x.data_ptr(), row_stride, a, gamma, beta, x_new, h, stats[0], stats[1], T, eps, p_drop, *seed)
         ctx.save_for_backward(u, wb, x_new, gamma, stats)
         ctx.meta = (p_drop, seed)
         return x_new, h
@@ -746,16 +811,25 @@ class _LinearAddLayerNorm(torch.autograd.Function):
         weight, bias, gamma_p, beta_p = ctx.params
         sink = _sink_for(weight, bias, gamma_p, beta_p)
         dparams = None if sink is not None else torch.empty((3, 256), dtype=torch.float32, device=xn.device)
-        if g_h is None:
-            g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
         period = 1
         cl = ctx.cls_link
         if cl is not None and cl.g is not None:  # the stream's only gradient: the CLS rows, from _ClsRows
             if g_x is not None:
                 raise RuntimeError("the residual stream entering the CLS-only layer has a second consumer")
             g_x, period, cl.g = cl.g, xn.shape[1], None
-        ws = nv.add_ln_bwd(xn.data_ptr(), 256, None if g_x is None else g_x.contiguous(), g_h.contiguous(), stats[0], stats[1],
-                           gamma, dx, da, dparams, T, p_drop, *seed, g_x_period=period)
+        pend = ctx.h_link.take() if ctx.h_link is not None else None
+        if pend is not None:  # the consumer of h left its input-gradient GEMM to this node: GEMM + LayerNorm backward in one launch
+            if g_h is not None:
+                raise RuntimeError("the normalised activation has a second consumer besides the linked Linear")
+            ws = nv.linear_add_ln_bwd(pend[0], pend[1], xn.data_ptr(), 256, None if g_x is None else g_x.contiguous(), stats[0],
+                                      stats[1], gamma, dx, da, p_drop, *seed, g_x_period=period)
+            if sink is None:
+                dparams = ws.sum(0).view(3, 256)
+        else:
+            if g_h is None:
+                g_h = torch.zeros(xn.shape, dtype=torch.bfloat16, device=xn.device)
+            ws = nv.add_ln_bwd(xn.data_ptr(), 256, None if g_x is None else g_x.contiguous(), g_h.contiguous(), stats[0], stats[1],
+                               gamma, dx, da, dparams, T, p_drop, *seed, g_x_period=period)
         if sink is not None:
             sink.add(gamma_p, ws, 768, 256, ws.shape[0])
             sink.add(beta_p, ws[:, 256:], 768, 256, ws.shape[0])
@@ -781,9 +855,9 @@ class _LinearAddLayerNorm(torch.autograd.Function):
                     du = (da2 @ wb if du is None else du).view(u.shape)
             if sink is not None:
                 _sink_weight(sink, weight, da2, u2)
-                return du, None, None, None, None, dx, None, None, None, None, None, None, None
+                return du, None, None, None, None, dx, None, None, None, None, None, None, None, None, None
             dw = _dweight(da2, u2)
-        return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None, None, None
+        return du, dw, dparams[2], None, None, dx, dparams[0], dparams[1], None, None, None, None, None, None, None
 
 
 class _LinearAddCast(torch.autograd.Function):
@@ -841,9 +915,10 @@ class _LinearReluDropout(torch.autograd.Function):
     gradient, nothing is launched for the activation; else ``g2048_relu_dropout_bwd``."""
 
     @staticmethod
-    def forward(ctx, h, weight, bias, wb, bb, p_drop, link=None):
+    def forward(ctx, h, weight, bias, wb, bb, p_drop, link=None, h_link=None, wt_packed=None):
         from ..g2048 import native as nv
 
+        ctx.h_link, ctx.wt_packed = h_link, wt_packed  # (HLink: the producer of h may run this node's input-gradient GEMM itself)
         h2 = h.reshape(-1, h.shape[-1])
         with torch.autocast("cuda", enabled=False):
             if _stationary_ok(h2, wb) and bias.dtype == torch.float32:
@@ -884,14 +959,16 @@ class _LinearReluDropout(torch.autograd.Function):
                 db_done = True
         with torch.autocast("cuda", enabled=False):
             dz2, h2 = dz.view(-1, dz.shape[-1]), h.reshape(-1, h.shape[-1])
-            dh = (dz2 @ wb).view(h.shape) if ctx.needs_input_grad[0] else None
+            dh = None
+            if ctx.needs_input_grad[0] and not (ctx.h_link is not None and ctx.h_link.offer(dz2, ctx.wt_packed)):
+                dh = (dz2 @ wb).view(h.shape)
             if sink is not None:
                 _sink_weight(sink, weight, dz2, h2)
                 if not db_done:  # the link delivered a finished bias gradient: let the sink copy it into place
                     sink.add(bias, db.contiguous(), db.numel(), db.numel(), 1)
-                return dh, None, None, None, None, None, None
+                return dh, None, None, None, None, None, None, None, None
             dw = _dweight(dz2, h2)
-        return dh, dw, (None if db_done else db), None, None, None, None
+        return dh, dw, (None if db_done else db), None, None, None, None, None, None
 
 
 def _fused_norm_ok(x: torch.Tensor, a) -> bool:
@@ -900,12 +977,12 @@ def _fused_norm_ok(x: torch.Tensor, a) -> bool:
             and (a is None or a.dtype == torch.bfloat16))
 
 
-def _add_norm(x: torch.Tensor, a, norm: nn.LayerNorm, p: float, training: bool):
-    """(x + dropout(a), LayerNorm(x + dropout(a))); ``a`` None: (x, LayerNorm(x))."""
+def _add_norm(x: torch.Tensor, a, norm: nn.LayerNorm, p: float, training: bool, h_link=None):
+    """(x + dropout(a), LayerNorm(x + dropout(a))); ``a`` None: (x, LayerNorm(x)).  ``h_link``: see ``HLink``."""
     if _fused_norm_ok(x, a):
         if a is None and _residual_rows(x)[0] is not x:  # a copy would be made: keep the caller's x as the stream
             return x, _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, 0.0)[1]
-        return _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, p if training else 0.0)
+        return _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, p if training else 0.0, h_link)
     if a is not None:
         x = x + F.dropout(a, p, training)
     return x, F.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)
@@ -963,12 +1040,13 @@ def _train_bf16(t: torch.Tensor, weight: torch.Tensor) -> bool:
             and torch.get_autocast_dtype("cuda") == torch.bfloat16)
 
 
-def _linear(x: torch.Tensor, weight: torch.Tensor, bias, wb=None, bb=None, relu: bool = False) -> torch.Tensor:
-    """``F.linear`` (``relu``: followed by ReLU), through the update path's autograd nodes under bf16 autocast with gradients."""
+def _linear(x: torch.Tensor, weight: torch.Tensor, bias, wb=None, bb=None, relu: bool = False, h_link=None, wt_packed=None) -> torch.Tensor:
+    """``F.linear`` (``relu``: followed by ReLU), through the update path's autograd nodes under bf16 autocast with gradients.
+    ``h_link`` / ``wt_packed``: see ``HLink`` (the producer of x may take over the input-gradient GEMM)."""
     if _train_bf16(x, weight):
         if relu and _LinearRelu.ok(x, weight, bias, wb, bb):
             return _LinearRelu.apply(x, weight, bias, wb, bb)
-        y = _LinearSplitK.apply(x, weight, bias, wb, bb)
+        y = _LinearSplitK.apply(x, weight, bias, wb, bb, h_link, wt_packed)
     else:
         y = F.linear(x, weight, bias)
     return F.relu(y) if relu else y

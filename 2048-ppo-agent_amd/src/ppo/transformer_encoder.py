@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..env_definitions import BOARD_DIM
-from .hip_ops import (Bf16Shadow, ClsLink, FFNLink, _AddLayerNorm, _ClsRows, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
+from .hip_ops import (Bf16Shadow, ClsLink, FFNLink, HLink, _AddLayerNorm, _ClsRows, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
                       _LinearAddCast, _LinearAddLayerNorm, _LinearReluDropout, _LinearSplitK, _add_norm, _fused_attention_ok, _fused_norm_ok,
                       _linear, _train_bf16, graph_seed_state)
 
@@ -80,7 +80,7 @@ class TransformerEncoder(nn.Module):
         (``Bf16Shadow``), else a list of None (``_linear`` then uses the masters directly)."""
         layers = self.encoder.layers
         if not _train_bf16(like, layers[0].linear1.weight):
-            return [[None] * 10 for _ in layers]
+            return [[None] * 14 for _ in layers]
         if self._shadow is None:
             ps = []
             for l in layers:
@@ -90,14 +90,24 @@ class TransformerEncoder(nn.Module):
             # [in, out] copies: linear2 of every layer (masked input-gradient GEMM); fragment-packed copies (tensor and transpose) of
             # out_proj, linear1 and linear2 of the LAST layer (the fused CLS tail, g2048_cls_tail_fwd / _bwd)
             # (+ out_proj^T of the layers in front of it: the input gradient of out_proj through g2048_linear_bf16)
+            # (+ for the layers in front of the last, at d_model 256: fragment-packed out_proj and linear2 - the forward operands of
+            # g2048_linear_add_ln_fwd - and fragment-packed TRANSPOSES of in_proj and linear1 - the operands of the input-gradient GEMM
+            # fused with the LayerNorm backward, g2048_linear_add_ln_bwd)
+            fuse = range(last) if self.d_model == 256 else range(0)
             self._shadow = Bf16Shadow(ps, transposed=[8 * i + 6 for i in range(len(layers))] + [8 * i + 2 for i in range(last)],
-                                      packed=[8 * last + 2, 8 * last + 4, 8 * last + 6])
+                                      packed=[8 * last + 2, 8 * last + 4, 8 * last + 6],
+                                      packed_only=[8 * i + o for i in fuse for o in (2, 6)],
+                                      packed_t_only=[8 * i + o for i in fuse for o in (0, 4)])
         v = self._shadow()
-        tv = self._shadow.tviews
-        return [v[8 * i:8 * i + 8] + [tv[8 * i + 6], tv.get(8 * i + 2)] for i in range(len(layers))]
+        tv, pv, ptv = self._shadow.tviews, self._shadow.pviews, self._shadow.ptviews
+        full = range(len(layers) - 1)  # (the last layer's packed copies belong to the fused CLS tail)
+        return [v[8 * i:8 * i + 8] + [tv[8 * i + 6], tv.get(8 * i + 2)]
+                + ([pv.get(8 * i + 2), pv.get(8 * i + 6), ptv.get(8 * i + 0), ptv.get(8 * i + 4)] if i in full else [None] * 4)
+                for i in range(len(layers))]
 
     def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor, h: torch.Tensor, next_norm,
-               cls_only: bool = False, sh=(None,) * 10, cls_link_out=None, cls_link_in=None, tail_heads=None):
+               cls_only: bool = False, sh=(None,) * 14, cls_link_out=None, cls_link_in=None, tail_heads=None, h_link_in=None,
+               h_link_out=None):
         """One pre-norm encoder layer.  ``h`` = norm1(x), already computed (by the previous layer's tail); returns
         (x_out, next_norm(x_out)) so that every residual add + dropout + LayerNorm is one fused kernel
         (``_add_norm``); ``next_norm`` None: (x_out, None).  With ``cls_only`` only the CLS row of the output is
@@ -122,7 +132,8 @@ class TransformerEncoder(nn.Module):
                 a = F.scaled_dot_product_attention(q.view(B, 1, H, D // H).transpose(1, 2), k.transpose(1, 2),
                                                    v.transpose(1, 2), dropout_p=p).transpose(1, 2).reshape(B, 1, D)
         else:
-            qkv = _linear(h, attn.in_proj_weight, attn.in_proj_bias, sh[0], sh[1])
+            # (h_link_in: the node that produced h runs this Linear's input-gradient GEMM inside its own LayerNorm backward)
+            qkv = _linear(h, attn.in_proj_weight, attn.in_proj_bias, sh[0], sh[1], h_link=h_link_in, wt_packed=sh[12])
             if _fused_attention_ok(qkv, S, D // H):
                 a = _AttnPacked.apply(qkv, H, p)
             else:
@@ -145,10 +156,11 @@ class TransformerEncoder(nn.Module):
                 and layer.linear1.out_features % 8 == 0 and layer.linear1.out_features <= 2048:
             # update path: out_proj + add + LayerNorm, linear1 + ReLU + dropout, linear2 + add + LayerNorm as three ops
             n2 = layer.norm2
+            mid = HLink() if sh[13] is not None else None  # out_proj's add + LayerNorm <-> linear1's input gradient
             x, h = _LinearAddLayerNorm.apply(a, attn.out_proj.weight, attn.out_proj.bias, sh[2], sh[3], x, n2.weight,
-                                             n2.bias, n2.eps, p, sh[9])
+                                             n2.bias, n2.eps, p, sh[9], None, None, mid, sh[10])
             link = FFNLink(p) if next_norm is not None else None
-            f = _LinearReluDropout.apply(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5], p, link)
+            f = _LinearReluDropout.apply(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5], p, link, mid, sh[13])
             if next_norm is None:
                 if sh[6] is not None and layer.linear2.bias is not None:
                     # the encoder's output: residual add + dropout + bf16 cast in one launch (the heads read bf16 anyway)
@@ -156,7 +168,7 @@ class TransformerEncoder(nn.Module):
                 f = _linear(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7])
                 return x + F.dropout(f, p, self.training), None
             return _LinearAddLayerNorm.apply(f, layer.linear2.weight, layer.linear2.bias, sh[6], sh[7], x, next_norm.weight,
-                                             next_norm.bias, next_norm.eps, p, sh[8], link, cls_link_out)
+                                             next_norm.bias, next_norm.eps, p, sh[8], link, cls_link_out, h_link_out, sh[11])
         a = _linear(a, attn.out_proj.weight, attn.out_proj.bias, sh[2], sh[3])
         x, h = _add_norm(x, a, layer.norm2, p, self.training)
         f = F.dropout(F.relu(_linear(h, layer.linear1.weight, layer.linear1.bias, sh[4], sh[5])), p, self.training)
@@ -194,7 +206,10 @@ class TransformerEncoder(nn.Module):
         layers = self.encoder.layers
         last = len(layers) - 1
         sh = self._bf16_weights(x)
-        x, h = _add_norm(x, None, layers[0].norm1, 0.0, self.training)
+        # h_links[i]: joins the node that produces layer i's normalised input with that layer's in_proj (whose fragment-packed
+        # transposed weight sh[i][12] exists for the layers in front of the last one): see hip_ops.HLink
+        h_links = [HLink() if sh[i][12] is not None else None for i in range(len(layers))]
+        x, h = _add_norm(x, None, layers[0].norm1, 0.0, self.training, h_link=h_links[0])
         # update path with a CLS-only last layer: its CLS-row gradient goes straight into the backward kernel of the layer
         # before it (ClsLink) instead of through a zero-filled [B, 17, 256] tensor
         cls_link = ClsLink() if (reduction == "cls" and last >= 1 and sh[0][0] is not None) else None
@@ -203,7 +218,8 @@ class TransformerEncoder(nn.Module):
                                cls_only=(reduction == "cls" and i == last), sh=sh[i],
                                cls_link_out=cls_link if i == last - 1 else None,
                                cls_link_in=cls_link if i == last else None,
-                               tail_heads=tail_heads if (i == last and self.encoder.norm is None) else None)
+                               tail_heads=tail_heads if (i == last and self.encoder.norm is None) else None,
+                               h_link_in=h_links[i], h_link_out=h_links[i + 1] if i < last else None)
             if isinstance(x, tuple):  # (logits, values) from the fused CLS tail
                 return x
         if self.encoder.norm is not None:

@@ -48,10 +48,10 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling is ~6290 GB/s
 STEP_BYTES = 50  # board 16 r + 16 w, action 4, key 8, reward 4, mask 1, done 1
 POLICY_STEP_BYTES = 93  # fused policy step: state 18 r + 18 w (+ ep_len 4 r/w), logits 16, value 4, trajectory 29
-POLICY_STEP_VALU_PER_WAVE = 1150  # k_policy_step<partitionable, AUTO=0> (ISA count)
+POLICY_STEP_VALU_PER_WAVE = 1150  # k_policy_step<partitionable, AUTO=0> (ISA count, NOTES.md 3)
 STEP_VALU_PER_WAVE = 554  # vector instructions per wave of k_step<partitionable> (ISA count = SQ_INSTS_VALU / SQ_WAVES)
 VALU_PEAK_GINSTR = 1024 * 2.4 / 2  # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction on a SIMD-32 = 1228.8 G/s
-# What k_step's OWN instruction mix can issue: its 554 vector instructions by opcode (hipcc -save-temps) priced with the
+# What k_step's OWN instruction mix can issue: its 554 vector instructions by opcode (hipcc -save-temps; NOTES.md 3) priced with the
 # per-opcode issue cost measured on this chip at 8 waves per SIMD (profiles/round1_valu_rate_microbench.txt: add / xor / and ~2.7-2.8
 # cycles per wave64 instruction, every three-operand, shift, permute or bit-field opcode 4.3-4.6):
 #   threefry x4: 80 alignbit x 4.52 + 78 xor x 2.72 + 95 add x 2.77 + 27 add3 x 4.59 + 20 xad x 4.56          = 1 052 cycles
@@ -299,7 +299,7 @@ def cpu_baseline(boards: int, total_seconds: float = 18.0):
                       f"threads; env + RNG + policy draw only (no policy network); C restatement of the Pgx 2048 env "
                       f"(oracle/g2048_oracle.c), bit-exact vs the reference's golden frames",
             "unpinned_semantics": "no reference artifact pins three env rules the oracle (and the kernels) restate from Pgx: the merge-reward "
-                                  "magnitude, -1 on an illegal action, the spawn on a full board going to cell 0 (DESIGN.md 4); rewards "
+                                  "magnitude, -1 on an illegal action, the spawn on a full board going to cell 0 (NOTES.md 4); rewards "
                                   "feed GAE and the loss",
             "cpu_model": model, "logical_cpus": os.cpu_count(), "physical_cores": phys, "matrix": matrix}
 

@@ -229,6 +229,28 @@ int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x
                      const float *rstd, const float *gamma, float *dx, void *da, float *dparams, float *workspace,
                      int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, int g_x_period, void *stream);
 
+/* ---- policy network (update): Linear (256 outputs) fused with the add + LayerNorm kernel behind it -------------- */
+
+/* x_new = x + dropout(u . W^T + bias);  h = bf16(LayerNorm(x_new) * gamma + beta) in ONE launch: g2048_linear_bf16 (N = 256)
+ * followed by g2048_add_ln_fwd, without the bf16 [T][256] tensor between them (reference: `x = x + dropout1(self_attn(...))` /
+ * `x = x + dropout2(linear2(...))` + the next sub-layer's norm, nn.TransformerEncoderLayer(norm_first=True) built at
+ * src/ppo/transformer_encoder.py:138-148).  u bf16 [T][K], leading dimension ldu (elements, multiple of 8); w_packed: the Linear's
+ * weight [256][K] as bf16 in the FRAGMENT-PACKED layout above (g2048_opt_step maintains such copies); K a multiple of 256; bias f32 [256]
+ * or NULL; the rest as g2048_add_ln_fwd (same dropout hash on the same element index: the two paths draw the same mask for the same
+ * seed).  The Linear's output is rounded to bf16 before dropout and the add, as the unfused pair does. */
+int g2048_linear_add_ln_fwd(const void *u, int64_t ldu, const void *w_packed, const float *bias, int K, const float *x,
+                            int64_t x_row_stride, const float *gamma, const float *beta, float *x_new, void *h, float *mean,
+                            float *rstd, int64_t T, float eps, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
+/* g_h = bf16(dy . Wt^T);  then g2048_add_ln_bwd on it: the input-gradient GEMM of the Linear that CONSUMED h (linear1: K = 1024,
+ * in_proj: K = 768) fused with the backward of the LayerNorm that produced h (reference: autograd of the same modules).
+ * dy bf16 [T][K]; wt_packed: the TRANSPOSE of that Linear's weight, [256][K], fragment-packed; da may be NULL (the LayerNorm had no
+ * branch); partial: f32 [g2048_linear_add_ln_bwd_partial_rows(T)][3][256] first-stage sums (dgamma | dbeta | column sums of da) for
+ * g2048_reduce_jobs. */
+int64_t g2048_linear_add_ln_bwd_partial_rows(int64_t T);
+int g2048_linear_add_ln_bwd(const void *dy, int64_t lddy, const void *wt_packed, int K, const float *x_norm, int64_t x_row_stride,
+                            const float *g_x, int g_x_period, const float *mean, const float *rstd, const float *gamma, float *dx,
+                            void *da, float *partial, int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
+
 /* ---- policy network (update): bias gradients ------------------------------------------------------------ */
 
 /* out[c] = sum_r x[r][c] for x bf16 (is_bf16 != 0) or f32 [T][N] with element stride row_stride between rows; f32

@@ -1025,7 +1025,7 @@ def test_linear_add_cast_node_matches_torch(dev):
 def test_no_garbage_collection_while_a_stream_is_capturing(dev, tmp_path, monkeypatch):
     """Both capture sites (the update's _GraphedFwdBwd and the MLP policy's rollout forward) run under capture.capture():
     with the collector's thresholds far below their defaults not one collection starts while the stream is capturing, although
-    earlier trainers with captured graphs are garbage at that moment (the situation of the recorded abort)."""
+    earlier trainers with captured graphs are garbage at that moment (the situation of the recorded abort, NOTES.md 3)."""
     import gc
 
     from src.ppo.capture import CollectionsWhileCapturing

@@ -1,5 +1,5 @@
 """Streaming write / read / copy rates of this MI355X through plain PyTorch kernels on buffers far larger than the 256 MB Infinity
-Cache: the reference point for the update's write-heavy kernels.  usage: python tools/hbm_rw_rates.py"""
+Cache: the reference point for the update's write-heavy kernels (NOTES.md 3).  usage: python tools/hbm_rw_rates.py"""
 import json
 
 import torch

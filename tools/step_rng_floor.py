@@ -1,6 +1,6 @@
 """k_step with the reference's RNG schedule stubbed out, next to the real kernel (diagnostic build, never the product library).
 
-VERDICT r2 task 5: DESIGN.md 3 claims that 300 of k_step's 554 vector instructions are the four threefry2x32 blocks the
+VERDICT r2 task 5: NOTES.md 3 claims that 300 of k_step's 554 vector instructions are the four threefry2x32 blocks the
 bit-exact RNG stream prescribes and that this, not the board logic, keeps the kernel below 60 % of HBM.  This builds
 csrc/g2048.hip with -DG2048_RNG_STUB (board_spawn takes the two key words as its random bits: same 50 bytes per env-step,
 same board logic, no threefry) into tools/_build/libg2048_rngstub.so, launches both kernels on the same 2^24 mid-game boards
