@@ -28,6 +28,7 @@
 // (80 MFMAs per SIMD = 2 560 cycles) is about what the chunk's 35 KB take to arrive at a CU's share of 6 TB/s.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -53,7 +54,10 @@ enum { RG_FWD = 0, RG_BWD = 1 };
 struct RowGemmArgs {
     const __bf16 *x;  // [T][K] GEMM input (u forward, dy backward), leading dimension ldx
     int64_t ldx;
-    const __bf16 *w;  // fragment-packed [256][K]
+    const __bf16 *w;  // fragment-packed [256][K] (or K columns of a wider packed matrix: w_tile_stride)
+    int64_t w_tile_stride;  // elements between the 32-row tiles of the packed weight: (K / 16) * 512 for a dense [256][K]
+    const uint16_t *gh_extra;  // backward: optional bf16 [T / extra_period][256] added to g_h on the rows tok % extra_period == 0
+    int extra_period;
     const float *bias;  // forward: the Linear's bias (f32 [256]) or null
     int64_t T;
     int K, tpw;
@@ -143,7 +147,7 @@ k_rowgemm(RowGemmArgs A) {
         // ---- weight fragments of this wave: row tile w, k-step 8 c + ks at ((w K/16 + 8 c + ks) 512 + 8 lane) elements.  ONE set of eight:
         // fragment ks of the next chunk is fetched right behind the five MFMAs that were the last to read fragment ks of this one
         // (seven k-steps = ~1 us ahead of its first use; a second set costs 32 registers that the kernel does not have)
-        const __bf16 *const wp = A.w + ((size_t)w * (A.K >> 4)) * 512 + lane * 8;
+        const __bf16 *const wp = A.w + (size_t)w * A.w_tile_stride + lane * 8;
         bf16x8 W[8];
         // B fragment of k-step ks, block b: row 32 b + r of the stage, piece (2 ks + h) ^ (r & 15) = 2 ks ^ (h ^ (r & 15))
         const uint32_t brow = (uint32_t)(r * (RG_KC * 2)), bx = (uint32_t)((h ^ (r & 15)) << 4);
@@ -185,26 +189,18 @@ k_rowgemm(RowGemmArgs A) {
         if (WPRE) { RG_LSTORE((P) ^ 1); }                                                                                  \
         lds_barrier();                                                                                                     \
     }
-        // (K is a multiple of 256: chunks come in pairs; the last pair is peeled: nothing left to prefetch)
-        for (int c = 0; c + 2 < n_chunks; c += 2) {
-            RG_CHUNK(0, c, 1, 1);
-            RG_CHUNK(1, c + 1, 1, 1);
-        }
-        RG_CHUNK(0, n_chunks - 2, 0, 1);
-        RG_CHUNK(1, n_chunks - 1, 0, 0);
-#undef RG_CHUNK
-#undef RG_FRAG
-#undef RG_GLOAD
-#undef RG_LSTORE
-
-        // ---- epilogue.  Wave w takes rows w, w + 8, ... of the tile; lane l holds features 4 l .. 4 l + 3 of a row.  The residual rows
-        // (forward: all of the wave's rows; backward: the first batch) are requested NOW, before the output tile is staged: they are in
-        // flight while the accumulators go to LDS and the workgroup meets at the barrier.  Rows past the tile are computed on the
+        // ---- epilogue state, declared in front of the LAST K-chunk: wave w takes rows w, w + 8, ... of the tile; lane l holds features
+        // 4 l .. 4 l + 3 of a row.  The residual rows of the first batch are requested under the last chunk's MFMAs (the registers of
+        // the X prefetch are free by then), the rest right after the output tile is staged.  Rows past the tile are computed on the
         // tile's last row and not stored - no control flow inside a batch.
         const bool norm = A.gamma != nullptr;
         const float4 gm = norm ? reinterpret_cast<const float4 *>(A.gamma)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
         auto row_tok = [&](int row) -> int64_t { return tok0 + (row < n_valid ? row : n_valid - 1); };
-        constexpr int BB = NB <= 3 ? RG_BATCH / 2 : 2, NBB = RG_RPW / BB;  // backward: rows per batch (two 16-byte loads per row), batches
+        // PIPE (the 96-token shape): loads of batch k + 1 in flight under the arithmetic of batch k, the first batch requested under the
+        // last K-chunk.  The 160-token shape has no registers for that next to its five accumulator tiles (every pipelined form spilled
+        // 40-280 registers): it loads a batch, works on it, loads the next.
+        constexpr bool PIPE = NB <= 3;
+        constexpr int BB = RG_BATCH / 2, NBB = RG_RPW / BB;  // backward: rows per batch (two 16-byte loads per row), batches
         static_assert(RG_RPW % BB == 0, "backward batches");
         float4 fv[MODE == RG_FWD ? RG_RPW : 1];
         float4 bx0[2][MODE == RG_BWD ? BB : 1], bg0[2][MODE == RG_BWD ? BB : 1];
@@ -224,17 +220,30 @@ k_rowgemm(RowGemmArgs A) {
                 }
             }
         };
-        // (the 160-token tile's five accumulator tiles leave no registers for loads in flight across the staging: it loads afterwards)
-        constexpr bool EARLY = NB <= 3;
-        auto first_loads = [&]() {
-            if (MODE == RG_FWD) {
+        auto fwd_load = [&](auto lo_c, auto hi_c) {
 #pragma unroll
-                for (int j = 0; j < RG_RPW; ++j) fv[j] = reinterpret_cast<const float4 *>(A.res + row_tok(w + RG_WAVES * j) * A.res_rs)[lane];
-            } else {
-                bwd_load(0, std::integral_constant<int, 0>{});
-            }
+            for (int j = decltype(lo_c)::value; j < decltype(hi_c)::value; ++j)
+                fv[j] = reinterpret_cast<const float4 *>(A.res + row_tok(w + RG_WAVES * j) * A.res_rs)[lane];
         };
-        if (EARLY) first_loads();
+        using I0 = std::integral_constant<int, 0>;
+        using IB = std::integral_constant<int, RG_BATCH>;
+        using IR = std::integral_constant<int, RG_RPW>;
+        // (K is a multiple of 256: chunks come in pairs; the last pair is peeled: nothing left to prefetch)
+        for (int c = 0; c + 2 < n_chunks; c += 2) {
+            RG_CHUNK(0, c, 1, 1);
+            RG_CHUNK(1, c + 1, 1, 1);
+        }
+        RG_CHUNK(0, n_chunks - 2, 0, 1);
+        if (PIPE) {  // (under the last chunk's MFMAs)
+            if (MODE == RG_FWD) fwd_load(I0{}, IB{});
+            else bwd_load(0, I0{});
+        }
+        RG_CHUNK(1, n_chunks - 1, 0, 0);
+#undef RG_CHUNK
+#undef RG_FRAG
+#undef RG_GLOAD
+#undef RG_LSTORE
+
         // output tile -> LDS as bf16 rows of 512 bytes, 16-byte chunk ch of row t at ch ^ (t & 31) (every wave is past the last chunk's
         // barrier: both stages are free)
 #pragma unroll
@@ -248,7 +257,10 @@ k_rowgemm(RowGemmArgs A) {
             }
         }
         lds_barrier();
-        if (!EARLY) first_loads();
+        if (MODE == RG_FWD) {
+            if (PIPE) fwd_load(IB{}, IR{});
+            else fwd_load(I0{}, IR{});
+        }
         auto tile_row = [&](int row) -> uint2 {
             return *reinterpret_cast<const uint2 *>(smem + row * 512 + ((((lane >> 1) ^ (row & 31))) << 4) + 8 * (lane & 1));
         };
@@ -311,14 +323,23 @@ k_rowgemm(RowGemmArgs A) {
             // one batch (parity P of the load registers): the NEXT batch's loads are issued before this one's arithmetic
             auto bwd_batch = [&](int k, auto parity) {
                 constexpr int P = decltype(parity)::value;
-                if (k + 1 < NBB && w + RG_WAVES * (k + 1) * BB < n_valid) bwd_load(k + 1, std::integral_constant<int, P ^ 1>{});
+                if (PIPE && k + 1 < NBB && w + RG_WAVES * (k + 1) * BB < n_valid) bwd_load(k + 1, std::integral_constant<int, P ^ 1>{});
                 float xh[BB][4], dxh[BB][4], c1[BB], c2[BB];
 #pragma unroll
                 for (int j = 0; j < BB; ++j) {
                     const int row = w + RG_WAVES * (k * BB + j), rowc = row < n_valid ? row : n_valid - 1;
                     const float ok = row < n_valid ? 1.f : 0.f;  // a clamped duplicate row adds nothing to the column sums
                     const uint2 gb = tile_row(rowc);
-                    const float gh[4] = {bf2f(gb.x & 0xFFFFu), bf2f(gb.x >> 16), bf2f(gb.y & 0xFFFFu), bf2f(gb.y >> 16)};
+                    float gh[4] = {bf2f(gb.x & 0xFFFFu), bf2f(gb.x >> 16), bf2f(gb.y & 0xFFFFu), bf2f(gb.y >> 16)};
+                    if (A.gh_extra) {  // (uniform) e.g. the CLS rows' share of the last layer's query projection
+                        const int64_t tk = tok0 + rowc;
+                        if (tk % A.extra_period == 0) {
+                            const uint2 eb = reinterpret_cast<const uint2 *>(A.gh_extra + (tk / A.extra_period) * RG_N)[lane];
+                            // (the unfused path adds in bf16: g_h = bf16(g_h + extra))
+                            gh[0] = bf2f(f2bf(gh[0] + bf2f(eb.x & 0xFFFFu))); gh[1] = bf2f(f2bf(gh[1] + bf2f(eb.x >> 16)));
+                            gh[2] = bf2f(f2bf(gh[2] + bf2f(eb.y & 0xFFFFu))); gh[3] = bf2f(f2bf(gh[3] + bf2f(eb.y >> 16)));
+                        }
+                    }
                     const float xs[4] = {bx0[P][j].x, bx0[P][j].y, bx0[P][j].z, bx0[P][j].w};
                     c1[j] = c2[j] = 0.f;
 #pragma unroll
@@ -362,10 +383,19 @@ k_rowgemm(RowGemmArgs A) {
                     }
                 }
             };
+            if (PIPE) {
 #pragma unroll
-            for (int k = 0; k < NBB; k += 2) {
-                if (w + RG_WAVES * k * BB < n_valid) bwd_batch(k, std::integral_constant<int, 0>{});
-                if (k + 1 < NBB && w + RG_WAVES * (k + 1) * BB < n_valid) bwd_batch(k + 1, std::integral_constant<int, 1>{});
+                for (int k = 0; k < NBB; k += 2) {
+                    if (w + RG_WAVES * k * BB < n_valid) bwd_batch(k, std::integral_constant<int, 0>{});
+                    if (k + 1 < NBB && w + RG_WAVES * (k + 1) * BB < n_valid) bwd_batch(k + 1, std::integral_constant<int, 1>{});
+                }
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < NBB; ++k) {
+                    if (w + RG_WAVES * k * BB >= n_valid) break;
+                    bwd_load(k, std::integral_constant<int, 0>{});
+                    bwd_batch(k, std::integral_constant<int, 0>{});
+                }
             }
             // this workgroup's column sums (one partial row per workgroup AND tile: a workgroup that walks several tiles adds them up)
 #pragma unroll
@@ -392,18 +422,21 @@ inline int rg_done() {
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }
 
-// Tile size.  A workgroup's K-loop only READS (this chip sustains ~3.9 TB/s of pure reads, tools/hbm_rw_rates.py) and its row pass mostly
-// WRITES, and a workgroup runs them one after the other - so at the update's size every workgroup gets TWO tiles (68 tokens at
-// T = 34 816: 512 tiles on 256 CUs): the stores of the first tile's row pass drain under the second tile's K-loop.  (One 136-token tile
-// per workgroup, the first version: 45.9 instead of XX us for linear2 + add + LayerNorm.)  Larger T: 160-token tiles, several rounds.
+// Tile size: ONE tile per workgroup when T allows it (136 tokens = 8 boards at T = 34 816: 256 workgroups, one round on 256 CUs), because
+// every tile streams the whole weight through its CU once - 512 KB from L2 at K = 1024 - and five token blocks per weight fragment
+// amortise that better than three.  Measured (linear2 + add + LayerNorm at T = 34 816, cold operands): one 136-token tile per workgroup
+// 45.9 us, two 68-token tiles (96-token shape) 55.2 us - the hope that the second tile's reads would overlap the first tile's stores did
+// not survive the doubled weight traffic.  G2048_RG_TWO_TILES=1 selects the two-tile policy (the A/B switch of that measurement).
 inline int rg_tpw(int64_t T, int *nb) {
-    int64_t t = (T + 511) / 512;
-    if (t <= 96) {
+    const char *e = getenv("G2048_RG_TWO_TILES");  // (read per call: the library keeps no latched state)
+    const bool two = e && e[0] == '1';
+    int64_t t = (T + 255) / 256;
+    if (two) t = (T + 511) / 512;
+    if (t <= 96 && (two || t <= 48)) {  // small T: the 96-token shape wastes fewer MFMA rows
         *nb = 3;
         return (int)(t < 32 ? 32 : t);
     }
     *nb = 5;
-    t = (T + 255) / 256;
     return (int)(t > 160 ? 160 : t);
 }
 
@@ -446,22 +479,27 @@ extern "C" int g2048_linear_add_ln_fwd(const void *u, int64_t ldu, const void *w
         return G2048_EINVAL;
     RowGemmArgs A{};
     A.x = (const __bf16 *)u; A.ldx = ldu; A.w = (const __bf16 *)w_packed; A.bias = bias; A.T = T; A.K = K;
+    A.w_tile_stride = (int64_t)(K >> 4) * 512; A.extra_period = 1;
     A.res = x; A.res_rs = x_row_stride; A.gamma = gamma; A.beta = beta; A.mean = mean; A.rstd = rstd; A.out_f32 = x_new;
     A.out_bf16 = (uint16_t *)h; A.eps = eps; A.inv_keep = 1.0f / (1.0f - p_drop); A.thr = (uint32_t)(p_drop * 16777216.0f);
     A.s0 = (uint32_t)seed; A.s1 = (uint32_t)(seed >> 32); A.seed_state = seed_state; A.g_x_period = 1;
     return rg_launch<RG_FWD>(A, (hipStream_t)stream);
 }
 
-extern "C" int g2048_linear_add_ln_bwd(const void *dy, int64_t lddy, const void *wt_packed, int K, const float *x_norm,
-                                       int64_t x_row_stride, const float *g_x, int g_x_period, const float *mean, const float *rstd,
-                                       const float *gamma, float *dx, void *da, float *partial, int64_t T, float p_drop, uint64_t seed,
-                                       const uint64_t *seed_state, void *stream) {
+extern "C" int g2048_linear_add_ln_bwd(const void *dy, int64_t lddy, const void *wt_packed, int64_t wt_tile_stride, int K,
+                                       const float *x_norm, int64_t x_row_stride, const float *g_x, int g_x_period, const void *g_h_extra,
+                                       int extra_period, const float *mean, const float *rstd, const float *gamma, float *dx, void *da,
+                                       float *partial, int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream) {
+    if (wt_tile_stride == 0) wt_tile_stride = (int64_t)(K >> 4) * 512;
+    if (wt_tile_stride < (int64_t)(K >> 4) * 512 || (wt_tile_stride & 7) || (g_h_extra && extra_period < 1) || ((uintptr_t)g_h_extra & 7))
+        return G2048_EINVAL;
     if (!rg_gemm_ok(dy, lddy, wt_packed, T, K) || !x_norm || !mean || !rstd || !gamma || !dx || !partial || g_x_period < 1 ||
         !(p_drop >= 0.f && p_drop < 1.f) || (x_row_stride & 3) ||
         (((uintptr_t)x_norm | (uintptr_t)g_x | (uintptr_t)gamma | (uintptr_t)dx) & 15) || ((uintptr_t)da & 7) || ((uintptr_t)partial & 3))
         return G2048_EINVAL;
     RowGemmArgs A{};
     A.x = (const __bf16 *)dy; A.ldx = lddy; A.w = (const __bf16 *)wt_packed; A.T = T; A.K = K;
+    A.w_tile_stride = wt_tile_stride; A.gh_extra = (const uint16_t *)g_h_extra; A.extra_period = extra_period < 1 ? 1 : extra_period;
     A.res = x_norm; A.res_rs = x_row_stride; A.g_x = g_x; A.g_x_period = g_x_period; A.gamma = gamma;
     A.mean = const_cast<float *>(mean); A.rstd = const_cast<float *>(rstd); A.out_f32 = dx; A.out_bf16 = (uint16_t *)da;
     A.partial = partial; A.inv_keep = 1.0f / (1.0f - p_drop); A.thr = da ? (uint32_t)(p_drop * 16777216.0f) : 0u;

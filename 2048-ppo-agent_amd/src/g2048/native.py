@@ -71,8 +71,8 @@ SIGNATURES = {
     "g2048_linear_add_ln_fwd": [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float,
                                 C.c_uint64, _vp, _vp],
     "g2048_linear_add_ln_bwd_partial_rows": [_i64],
-    "g2048_linear_add_ln_bwd": [_vp, _i64, _vp, _i32, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float,
-                                C.c_uint64, _vp, _vp],
+    "g2048_linear_add_ln_bwd": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                C.c_float, C.c_uint64, _vp, _vp],
     "g2048_add_ln_bwd_workspace_floats": [_i64],
     "g2048_add_ln_bwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp,
                          _i32, _vp],
@@ -376,15 +376,19 @@ def add_ln_bwd(xn_ptr: int, x_row_stride: int, g_x, g_h, mean, rstd, gamma, dx, 
     return ws.view(-1, 768) if dparams is None else None
 
 
-def rowgemm_ok(u2: torch.Tensor, w_packed: torch.Tensor) -> bool:
+def rowgemm_ok(u2: torch.Tensor, w_packed: torch.Tensor, tile_stride: int = 0) -> bool:
     """Operands ``g2048_linear_add_ln_fwd / _bwd`` take: u2 bf16 [T, K] with unit column stride, K a multiple of 256, the packed weight
-    a flat bf16 tensor of 256 * K elements."""
+    a flat bf16 tensor of 256 * K elements - or, with ``tile_stride`` (elements between the 32-row tiles of a WIDER packed matrix), a
+    flat view that starts at the first of K / 16 consecutive k-steps of it."""
     if u2.dim() != 2 or not u2.is_cuda or u2.dtype != torch.bfloat16 or u2.stride(1) != 1:
         return False
     T, K = u2.shape
+    span = 256 * K if not tile_stride else 7 * int(tile_stride) + (K // 16) * 512
     return (T > 0 and K % 256 == 0 and 256 <= K <= 4096 and u2.stride(0) >= K and u2.stride(0) % 8 == 0 and u2.data_ptr() % 16 == 0
             and w_packed is not None and w_packed.is_cuda and w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
-            and w_packed.numel() == 256 * K and w_packed.data_ptr() % 16 == 0 and 160 * u2.stride(0) * 2 < 2 ** 31)
+            and (w_packed.numel() == span if not tile_stride else (w_packed.numel() >= span and tile_stride >= (K // 16) * 512
+                                                                  and tile_stride % 8 == 0))
+            and w_packed.data_ptr() % 16 == 0 and 160 * u2.stride(0) * 2 < 2 ** 31)
 
 
 def linear_add_ln_fwd(u2, w_packed, bias, x_ptr: int, x_row_stride: int, gamma, beta, x_new, h, mean, rstd, eps: float,
@@ -403,18 +407,21 @@ def linear_add_ln_fwd(u2, w_packed, bias, x_ptr: int, x_row_stride: int, gamma, 
 
 
 def linear_add_ln_bwd(dy2, wt_packed, xn_ptr: int, x_row_stride: int, g_x, mean, rstd, gamma, dx, da, p_drop: float, seed: int,
-                      seed_state: int = 0, g_x_period: int = 1):
+                      seed_state: int = 0, g_x_period: int = 1, tile_stride: int = 0, g_h_extra=None, extra_period: int = 1):
     """g_h = bf16(dy2 Wt^T) and the add+LayerNorm backward on it in one launch (``g2048_linear_add_ln_bwd``) -> f32 [rows, 768] partial
     sums (dgamma | dbeta | column sums of da) for ``reduce_jobs``.  wt_packed: the fragment-packed TRANSPOSE [256][K] of the weight of
-    the Linear that consumed h."""
-    if not rowgemm_ok(dy2, wt_packed):
+    the Linear that consumed h (``tile_stride``: see ``rowgemm_ok``).  ``g_h_extra`` bf16 [T / extra_period, 256]: added to g_h on the
+    rows tok % extra_period == 0."""
+    if not rowgemm_ok(dy2, wt_packed, tile_stride):
         raise NativeError(f"linear_add_ln_bwd: operands {tuple(dy2.shape)} (strides {dy2.stride()}) x packed {wt_packed.numel()} not supported")
     T, K = dy2.shape
     bf = torch.bfloat16
     ws = torch.empty((int(load().g2048_linear_add_ln_bwd_partial_rows(T)), 768), dtype=f32, device=dx.device)
-    _check(load().g2048_linear_add_ln_bwd(dy2.data_ptr(), dy2.stride(0), wt_packed.data_ptr(), K, xn_ptr, int(x_row_stride),
-                                          _dev(g_x, f32, 256 * (T // g_x_period), "g_x", optional=True), int(g_x_period),
-                                          _dev(mean, f32, T, "mean"), _dev(rstd, f32, T, "rstd"), _dev(gamma, f32, 256, "gamma"),
+    _check(load().g2048_linear_add_ln_bwd(dy2.data_ptr(), dy2.stride(0), wt_packed.data_ptr(), int(tile_stride), K, xn_ptr,
+                                          int(x_row_stride), _dev(g_x, f32, 256 * (T // g_x_period), "g_x", optional=True),
+                                          int(g_x_period),
+                                          _dev(g_h_extra, bf, 256 * (T // max(int(extra_period), 1)), "g_h_extra", optional=True),
+                                          int(extra_period), _dev(mean, f32, T, "mean"), _dev(rstd, f32, T, "rstd"), _dev(gamma, f32, 256, "gamma"),
                                           _dev(dx, f32, 256 * T, "dx"), _dev(da, bf, 256 * T, "da", optional=True), ws.data_ptr(), T,
                                           float(p_drop), int(seed), seed_state or None, _stream()), "g2048_linear_add_ln_bwd")
     return ws

@@ -285,13 +285,16 @@ class HLink:
     def __init__(self):
         self.armed, self.pending = False, None
 
-    def offer(self, dy2: torch.Tensor, wt_packed) -> bool:
-        """Called by the consumer's backward: True if the producer will compute the input gradient itself."""
+    def offer(self, dy2: torch.Tensor, wt_packed, tile_stride: int = 0, extra=None, extra_period: int = 1) -> bool:
+        """Called by the consumer's backward: True if the producer will compute the input gradient itself.  ``tile_stride``: the packed
+        weight is K columns of a wider packed matrix (``native.rowgemm_ok``); ``extra`` bf16 [T / extra_period, 256]: added to the
+        gradient on the rows t % extra_period == 0 (the CLS rows' share of the last layer's query projection)."""
         from ..g2048 import native as nv
 
-        if not self.armed or wt_packed is None or self.pending is not None or not _rowgemm_on() or not nv.rowgemm_ok(dy2, wt_packed):
+        if (not self.armed or wt_packed is None or self.pending is not None or not _rowgemm_on()
+                or not nv.rowgemm_ok(dy2, wt_packed, tile_stride)):
             return False
-        self.pending = (dy2, wt_packed)
+        self.pending = (dy2, wt_packed, dict(tile_stride=int(tile_stride), g_h_extra=extra, extra_period=int(extra_period)))
         return True
 
     def take(self):
@@ -340,7 +343,9 @@ def _deferred_dweight(sink, weight, bias, dy2, x2, w_offset: int = 0, b_offset: 
     """A minibatch-sized token axis: the product joins the sink's grouped launch.  8 token slices (one per XCD): the launch as a whole
     fills the chip (~1 200 workgroups at minibatch 2048), so a product needs no more - measured 16 / 32 slices per product: 259 us for
     the launch + 40 us for the reduction of the partials, 8 slices: 250 + 32."""
-    if x2.shape[0] < 16384:
+    # (from 2 048 rows on: the 2048-row products of the CLS-only layer's query projection and of the MLP policy's 512 x 512 layers
+    # join the launch as well - each was a batched GEMM node of 8-14 us of its own)
+    if x2.shape[0] < 2048:
         return False
     from ..g2048 import native as nv
 
@@ -509,7 +514,8 @@ class _InProjCls(torch.autograd.Function):
     of the update takes the [B, 1, D] view with row stride 17 * D as an operand (NOTES.md 3, "the 02:59 fault")."""
 
     @staticmethod
-    def forward(ctx, h, weight, bias, wb, bb):
+    def forward(ctx, h, weight, bias, wb, bb, h_link=None, wt_packed=None):
+        ctx.h_link, ctx.wt_packed = h_link, wt_packed  # (HLink: the producer of h may run the K/V input-gradient GEMM itself)
         B, S, D = h.shape
         h_cls = h[:, 0].contiguous()
         q = F.linear(h_cls, wb[:D], bb[:D]).view(B, 1, D)
@@ -529,16 +535,29 @@ class _InProjCls(torch.autograd.Function):
         h, h_cls, wb = ctx.saved_tensors
         B, S, D = h.shape
         dq2, dkv2 = dq.reshape(B, D).contiguous(), dkv.reshape(B * S, 2 * D).contiguous()
-        dh = (dkv2 @ wb[D:]).view(B, S, D)
-        dh0 = dh[:, 0]  # [B, D] with row stride S * D: the CLS rows receive the query's gradient in the GEMM's epilogue
-        torch.addmm(dh0, dq2, wb[:D], out=dh0)
+        dh = None
+        link, wtp = ctx.h_link, ctx.wt_packed
+        if link is not None and wtp is not None and D == 256:
+            # the node that produced h runs dkv . W_kv inside its LayerNorm backward (g2048_linear_add_ln_bwd): W_kv^T = columns
+            # D .. 3 D of the packed in_proj^T [256][3 D] (k-steps D / 16 onwards, tile stride 3 D / 16 fragments), and the CLS rows' share
+            # of the query projection travels as an extra term on every S-th row
+            if link.offer(dkv2, wtp[(D // 16) * 512:], tile_stride=(3 * D // 16) * 512, extra=(dq2 @ wb[:D]).contiguous(), extra_period=S):
+                dh = None
+            else:
+                link = None
+        else:
+            link = None
+        if link is None:
+            dh = (dkv2 @ wb[D:]).view(B, S, D)
+            dh0 = dh[:, 0]  # [B, D] with row stride S * D: the CLS rows receive the query's gradient in the GEMM's epilogue
+            torch.addmm(dh0, dq2, wb[:D], out=dh0)
         weight, bias = ctx.params
         sink = _sink_for(weight, bias)
         if sink is not None:  # the four pieces land in their slices of the in_proj gradients
             _sink_weight(sink, weight, dq2, h_cls, 0)
             _sink_bias(sink, bias, dq2, 0)
             _sink_weight_bias(sink, weight, bias, dkv2, h.view(B * S, D), D * D, D)
-            return dh, None, None, None, None
+            return dh, None, None, None, None, None, None
 
         def weight_grads():
             dw = torch.empty((3 * D, D), dtype=torch.float32, device=h.device)
@@ -550,7 +569,7 @@ class _InProjCls(torch.autograd.Function):
             return dw, db
 
         dw, db = weight_grads()
-        return dh, dw, db, None, None
+        return dh, dw, db, None, None, None, None
 
 
 def _seed() -> int:
@@ -705,7 +724,8 @@ class _AddLayerNorm(torch.autograd.Function):
         if pend is not None:  # the consumer of h left its input-gradient GEMM to this node: GEMM + LayerNorm backward in one launch
             if g_h is not None:
                 raise RuntimeError("the normalised activation has a second consumer besides the linked Linear")
-            ws = nv.linear_add_ln_bwd(pend[0], pend[1], xn.data_ptr(), row_stride, g_x, stats[0], stats[1], gamma, dx, da, p_drop, *seed)
+            ws = nv.linear_add_ln_bwd(pend[0], pend[1], xn.data_ptr(), row_stride, g_x, stats[0], stats[1], gamma, dx, da, p_drop, *seed,
+                                      **pend[2])
             dparams = None if sink is not None else ws.sum(0).view(3, 256)
         else:
             if g_h is None:
@@ -822,7 +842,7 @@ class _LinearAddLayerNorm(torch.autograd.Function):
             if g_h is not None:
                 raise RuntimeError("the normalised activation has a second consumer besides the linked Linear")
             ws = nv.linear_add_ln_bwd(pend[0], pend[1], xn.data_ptr(), 256, None if g_x is None else g_x.contiguous(), stats[0],
-                                      stats[1], gamma, dx, da, p_drop, *seed, g_x_period=period)
+                                      stats[1], gamma, dx, da, p_drop, *seed, g_x_period=period, **pend[2])
             if sink is None:
                 dparams = ws.sum(0).view(3, 256)
         else:

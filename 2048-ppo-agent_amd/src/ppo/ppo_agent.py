@@ -16,9 +16,17 @@ from .hip_ops import TAIL_PARAM_ORDER, Bf16Shadow, TailBufferCache, TailPlan, _C
 from .transformer_encoder import TransformerEncoder
 
 
+_ARANGE = {}
+
+
 def _one_hot(boards: torch.Tensor, classes: int, dtype) -> torch.Tensor:
-    """[B, 16] integer boards -> [B, 16, classes] one-hot without the host-side range check of F.one_hot."""
-    return (boards.unsqueeze(-1) == torch.arange(classes, device=boards.device, dtype=boards.dtype)).to(dtype)
+    """[B, 16] integer boards -> [B, 16, classes] one-hot without the host-side range check of F.one_hot.  (The class index row is
+    cached per device: built per call it is one more launch in every forward of the MLP policy, whose update is launch-bound.)"""
+    key = (boards.device, boards.dtype, classes)
+    ar = _ARANGE.get(key)
+    if ar is None:
+        ar = _ARANGE[key] = torch.arange(classes, device=boards.device, dtype=boards.dtype)
+    return (boards.unsqueeze(-1) == ar).to(dtype)
 
 
 def _head(d_in: int, hidden: int, d_out: int) -> nn.Sequential:
@@ -255,10 +263,12 @@ class MLPAgent(_ActorCritic):
     def features(self, observations):
         if observations.dtype in (torch.uint8, torch.int16, torch.int32, torch.int64):
             if torch.is_grad_enabled() and self.trunk_in.weight.requires_grad:
-                oh = _one_hot(observations, self.observation_dim, self.trunk_in.weight.dtype).flatten(1)
                 ps = (self.trunk_in.weight, self.trunk_in.bias, self.trunk_hidden.weight, self.trunk_hidden.bias)
                 sh = (None,) * 4
-                if _train_bf16(oh, ps[0]):  # pre-cast bf16 shadows (kept current by the optimiser kernel), Linear+ReLU as one node
+                bf16_path = _train_bf16(observations, ps[0])
+                # (on the bf16 update path the one-hot is built in bf16 at once: exact, and one cast launch less per minibatch)
+                oh = _one_hot(observations, self.observation_dim, torch.bfloat16 if bf16_path else ps[0].dtype).flatten(1)
+                if bf16_path:  # pre-cast bf16 shadows (kept current by the optimiser kernel), Linear+ReLU as one node
                     if self._trunk_shadow is None:
                         self._trunk_shadow = Bf16Shadow(list(ps))
                     sh = self._trunk_shadow()

@@ -149,7 +149,9 @@ class _GraphedFwdBwd:
         trainer._capturing_allreduce = trainer._early_armed = bool(capture_allreduce)
         try:
             with capture_graph(self.graph):
-                seed_word.add_(1)  # new dropout masks on every replay (the HIP kernels read it at run time)
+                if any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in trainer.agent.modules()):
+                    seed_word.add_(1)  # new dropout masks on every replay (the HIP kernels read it at run time); an agent
+                    # without dropout (the MLP policy) does not pay the launch
                 self.out = self._fwd_bwd()
                 if trainer._flat_grad is not None:
                     trainer._collect_grads(point_grads=False)  # graph-owned gradients -> all-reduce bucket, one copy

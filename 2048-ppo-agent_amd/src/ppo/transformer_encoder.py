@@ -97,12 +97,13 @@ class TransformerEncoder(nn.Module):
             self._shadow = Bf16Shadow(ps, transposed=[8 * i + 6 for i in range(len(layers))] + [8 * i + 2 for i in range(last)],
                                       packed=[8 * last + 2, 8 * last + 4, 8 * last + 6],
                                       packed_only=[8 * i + o for i in fuse for o in (2, 6)],
-                                      packed_t_only=[8 * i + o for i in fuse for o in (0, 4)])
+                                      packed_t_only=[8 * i + o for i in fuse for o in (0, 4)] + ([8 * last] if self.d_model == 256 and last >= 1 else []))
         v = self._shadow()
         tv, pv, ptv = self._shadow.tviews, self._shadow.pviews, self._shadow.ptviews
         full = range(len(layers) - 1)  # (the last layer's packed copies belong to the fused CLS tail)
         return [v[8 * i:8 * i + 8] + [tv[8 * i + 6], tv.get(8 * i + 2)]
-                + ([pv.get(8 * i + 2), pv.get(8 * i + 6), ptv.get(8 * i + 0), ptv.get(8 * i + 4)] if i in full else [None] * 4)
+                + ([pv.get(8 * i + 2), pv.get(8 * i + 6), ptv.get(8 * i + 0), ptv.get(8 * i + 4)] if i in full
+                   else [None, None, ptv.get(8 * i + 0), None])  # (last layer: in_proj^T for the CLS-only K/V input gradient)
                 for i in range(len(layers))]
 
     def _layer(self, layer: nn.TransformerEncoderLayer, x: torch.Tensor, h: torch.Tensor, next_norm,
@@ -120,7 +121,7 @@ class TransformerEncoder(nn.Module):
         if cls_only:
             w, b = attn.in_proj_weight, attn.in_proj_bias
             if sh[0] is not None and h.dtype == torch.bfloat16:
-                q, kv = _InProjCls.apply(h, w, b, sh[0], sh[1])
+                q, kv = _InProjCls.apply(h, w, b, sh[0], sh[1], h_link_in, sh[12])
             else:
                 q = _linear(h[:, :1], w[:D], b[:D])
                 kv = _linear(h, w[D:], b[D:])

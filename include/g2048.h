@@ -243,13 +243,17 @@ int g2048_linear_add_ln_fwd(const void *u, int64_t ldu, const void *w_packed, co
                             float *rstd, int64_t T, float eps, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
 /* g_h = bf16(dy . Wt^T);  then g2048_add_ln_bwd on it: the input-gradient GEMM of the Linear that CONSUMED h (linear1: K = 1024,
  * in_proj: K = 768) fused with the backward of the LayerNorm that produced h (reference: autograd of the same modules).
- * dy bf16 [T][K]; wt_packed: the TRANSPOSE of that Linear's weight, [256][K], fragment-packed; da may be NULL (the LayerNorm had no
- * branch); partial: f32 [g2048_linear_add_ln_bwd_partial_rows(T)][3][256] first-stage sums (dgamma | dbeta | column sums of da) for
- * g2048_reduce_jobs. */
+ * dy bf16 [T][K]; wt_packed: the TRANSPOSE of that Linear's weight, [256][K], fragment-packed - or K consecutive columns of a wider
+ * packed matrix [256][K'] (point at the first k-step and pass wt_tile_stride = (K' / 16) * 512, the distance in elements between its
+ * 32-row tiles; 0 = dense): the K/V rows of a packed in_proj^T.  g_h_extra (bf16 [T / extra_period][256] or NULL) is added to g_h on
+ * the rows tok % extra_period == 0 (rounded to bf16 again, as an addmm into the bf16 gradient would): the CLS rows' share of the
+ * last layer's query projection.  da may be NULL (the LayerNorm had no branch); partial: f32
+ * [g2048_linear_add_ln_bwd_partial_rows(T)][3][256] first-stage sums (dgamma | dbeta | column sums of da) for g2048_reduce_jobs. */
 int64_t g2048_linear_add_ln_bwd_partial_rows(int64_t T);
-int g2048_linear_add_ln_bwd(const void *dy, int64_t lddy, const void *wt_packed, int K, const float *x_norm, int64_t x_row_stride,
-                            const float *g_x, int g_x_period, const float *mean, const float *rstd, const float *gamma, float *dx,
-                            void *da, float *partial, int64_t T, float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
+int g2048_linear_add_ln_bwd(const void *dy, int64_t lddy, const void *wt_packed, int64_t wt_tile_stride, int K, const float *x_norm,
+                            int64_t x_row_stride, const float *g_x, int g_x_period, const void *g_h_extra, int extra_period,
+                            const float *mean, const float *rstd, const float *gamma, float *dx, void *da, float *partial, int64_t T,
+                            float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
 
 /* ---- policy network (update): bias gradients ------------------------------------------------------------ */
 

@@ -114,6 +114,34 @@ def test_linear_add_ln_bwd_equals_the_unfused_pair(dev, T, K, period, with_da):
     assert 0 < ws.shape[0] <= 256 and ws.shape[1] == 768
 
 
+def test_linear_add_ln_bwd_strided_packed_weight_and_extra_rows(dev):
+    """The CLS-only last layer's case: the weight is K = 512 columns (the K/V rows of in_proj) of a packed [256][768] transpose, and
+    every 17th row receives an extra bf16 term (the query projection's share) - against the unfused sequence GEMM, addmm into the
+    CLS rows, g2048_add_ln_bwd with the CLS-row residual gradient (period 17)."""
+    B, S, D = 2048, 17, 256
+    T = B * S
+    g = torch.Generator(device="cpu").manual_seed(321)
+    dkv = (torch.randn(T, 2 * D, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    w_in = (torch.randn(3 * D, D, generator=g) / D ** 0.5).to(torch.bfloat16).to(dev)  # in_proj weight [768][256]
+    extra = (torch.randn(B, D, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    xn = torch.randn(T, D, generator=g).to(dev)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    g_x = torch.randn(B, D, generator=g).to(dev)  # CLS rows only
+    mean, rstd = xn.mean(1).contiguous(), (1 / torch.sqrt(xn.var(1, unbiased=False) + 1e-5)).contiguous()
+    wtp = nv.pack_fragments(w_in.t().contiguous())  # [256][768] packed
+    dx, da = torch.empty_like(xn), torch.empty(T, D, dtype=torch.bfloat16, device=dev)
+    ws = nv.linear_add_ln_bwd(dkv, wtp[(D // 16) * 512:], xn.data_ptr(), D, g_x, mean, rstd, gamma, dx, da, 0.1, 77, g_x_period=S,
+                              tile_stride=(3 * D // 16) * 512, g_h_extra=extra, extra_period=S)
+    g_h = (dkv.float() @ w_in[D:].float()).to(torch.bfloat16)
+    g_h[::S] = (g_h[::S].float() + extra.float()).to(torch.bfloat16)
+    dx_u, da_u = torch.empty_like(xn), torch.empty_like(da)
+    ws_u = nv.add_ln_bwd(xn.data_ptr(), D, g_x, g_h, mean, rstd, gamma, dx_u, da_u, None, T, 0.1, 77, g_x_period=S)
+    assert ((dx - dx_u).norm() / dx_u.norm()).item() < 4e-3
+    assert ((dx[::S] - dx_u[::S]).norm() / dx_u[::S].norm()).item() < 4e-3, "the CLS rows (extra term + residual gradient)"
+    assert ((da.float() - da_u.float()).norm() / da_u.float().norm()).item() < 6e-3
+    assert ((ws.sum(0) - ws_u.sum(0)).norm() / ws_u.sum(0).norm()).item() < 1e-2
+
+
 def test_rowgemm_refuses_what_it_cannot_take(dev):
     u = torch.zeros(64, 384, dtype=torch.bfloat16, device=dev)
     assert not nv.rowgemm_ok(u, torch.zeros(256 * 384, dtype=torch.bfloat16, device=dev))       # K not a multiple of 256
@@ -166,7 +194,8 @@ def test_agent_update_path_with_and_without_the_fused_launches(dev, monkeypatch)
     lo1, va1, g1, c1 = run(True)
     lo0, va0, g0, c0 = run(False)
     # 3 full layers: out_proj and linear2 forward; in the backward linear1's and in_proj's input gradients
-    assert c1 == {"fwd": 6, "bwd": 6} and c0 == {"fwd": 0, "bwd": 0}, (c1, c0)
+    # (+ the CLS-only last layer's K/V input gradient, fused into the LayerNorm backward of the layer in front of it)
+    assert c1 == {"fwd": 6, "bwd": 7} and c0 == {"fwd": 0, "bwd": 0}, (c1, c0)
     assert (lo1 - lo0).abs().max().item() < 0.03 and (va1 - va0).abs().max().item() < 0.03
     # The two paths differ in the summation order of the K > 256 GEMMs only, i.e. by one bf16 rounding step on some elements of a
     # Linear's output - but three ReLU layers downstream a flipped pre-activation sign moves a gradient tensor by a few per cent

@@ -47,7 +47,7 @@ for K in (256, 768, 1024):
                       x_new=torch.empty(T, 256, device=dev), h=torch.empty(T, 256, dtype=bf, device=dev), a=torch.empty(T, 256, dtype=bf, device=dev),
                       mean=torch.zeros(T, device=dev), rstd=torch.ones(T, device=dev), dx=torch.empty(T, 256, device=dev),
                       da=torch.empty(T, 256, dtype=bf, device=dev)))
-    p, seed = 0.1, 12345
+    p, seed = float(os.environ.get("P_DROP", "0.1")), 12345
 
     def fwd_fused(i):
         s = S[i]
