@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["g2048.hip", "g2048_policy.hip", "g2048_attention.hip", "g2048_layernorm.hip", "g2048_ppo_loss.hip",
-           "g2048_linear.hip", "g2048_optim.hip", "g2048_reduce.hip", "g2048_tail.hip", "g2048_dweight.hip", "g2048_rowgemm.hip"]
+           "g2048_linear.hip", "g2048_optim.hip", "g2048_reduce.hip", "g2048_tail.hip", "g2048_dweight.hip", "g2048_rowgemm.hip", "g2048_mlp.hip"]
 HEADERS = [os.path.join(CSRC, "g2048_device.h"), os.path.join(CSRC, "g2048_colsum_final.h"), os.path.join(CSRC, "g2048_mfma.h"),
            os.path.join(HERE, "..", "include", "g2048.h")]
 OBJDIR = os.path.join(HERE, "build")

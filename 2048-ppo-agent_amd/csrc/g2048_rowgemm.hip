@@ -100,7 +100,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
-template <int MODE, int NB>
+template <int MODE, int NB, int NCH>  // NCH = K / 128: the K-loop is unrolled over its chunks (every prefetch decision at compile time)
 __global__ void __launch_bounds__(RG_THREADS, 2)
 k_rowgemm(RowGemmArgs A) {
     constexpr int RG_NB = NB, RG_TT = RgShape<NB>::TT, RG_STAGE = RgShape<NB>::STAGE, RG_PIECES = RgShape<NB>::PIECES;
@@ -116,7 +116,6 @@ k_rowgemm(RowGemmArgs A) {
         s0 ^= (uint32_t)s * 0x9E3779B1u;
         s1 += (uint32_t)(s >> 32) * 0x85EBCA77u + (uint32_t)s;
     }
-    const int n_chunks = A.K / RG_KC;
     const int64_t n_tiles = (A.T + A.tpw - 1) / A.tpw;
     if (tid < RG_N) bias_l[tid] = (MODE == RG_FWD && A.bias) ? A.bias[tid] : 0.f;
 
@@ -134,62 +133,44 @@ k_rowgemm(RowGemmArgs A) {
         }
         const uint32_t loff0 = (uint32_t)(row0 * (RG_KC * 2) + ((pc ^ (row0 & 15)) << 4));
         const char *const xg = reinterpret_cast<const char *>(A.x + tok0 * A.ldx);
-        // chunk c of the X tile travels global -> G[c & 1] -> LDS stage c & 1.  (Indexed with compile-time constants only, and a NATIVE
-        // vector type: HIP's uint4 struct is copied by memcpy across address spaces, which kept the array in scratch memory - and a
-        // scratch store of a register that a global load is still filling waits for the load right behind its issue.)
-        u32x4 G[2][RG_PIECES];
-#define RG_GLOAD(P, c)                                                                                                    \
+        // chunk c of the X tile travels global -> G[c % 3] -> LDS stage c & 1: THREE chunks ahead in registers, two stages in LDS.  The
+        // K-loop is bound by the latency of its HBM reads (2.3 us per chunk = 15 GB/s per CU with two chunks in flight, round 4's first
+        // form): the bytes in flight are what buys bandwidth, and the registers for the third chunk come from a four-fragment weight
+        // ring (instead of eight) and three B fragments ahead (instead of five).  (Indexed with compile-time constants only, and a
+        // NATIVE vector type: HIP's uint4 struct is copied by memcpy across address spaces, which kept the array in scratch memory - and
+        // a scratch store of a register that a global load is still filling waits for the load right behind its issue.)
+        u32x4 G[3][RG_PIECES];
+        // (kc: the current chunk, advanced at run time and hidden from constant folding - with
+        // every chunk's addresses known at compile time the compiler computes all 40 of them up front and keeps them in registers)
+        unsigned kc = 0;  // the chunk the K loop is at
+#define RG_GLOAD(P, ahead)                                                                                                \
     _Pragma("unroll") for (int j = 0; j < RG_PIECES; ++j) G[P][j] =                                                       \
-        *reinterpret_cast<const u32x4 *>(xg + goff[j] + (size_t)(c) * (RG_KC * 2))
-#define RG_LSTORE(P)                                                                                                      \
+        *reinterpret_cast<const u32x4 *>(xg + goff[j] + (size_t)(kc + (ahead)) * (RG_KC * 2))
+#define RG_LSTORE(P, ST)                                                                                                  \
     _Pragma("unroll") for (int j = 0; j < RG_PIECES; ++j)                                                                 \
-        *reinterpret_cast<u32x4 *>(smem + (P) * RG_STAGE + loff0 + j * (32 * RG_KC * 2)) = G[P][j]
-        // ---- weight fragments of this wave: row tile w, k-step 8 c + ks at ((w K/16 + 8 c + ks) 512 + 8 lane) elements.  ONE set of eight:
-        // fragment ks of the next chunk is fetched right behind the five MFMAs that were the last to read fragment ks of this one
-        // (seven k-steps = ~1 us ahead of its first use; a second set costs 32 registers that the kernel does not have)
+        *reinterpret_cast<u32x4 *>(smem + (ST) * RG_STAGE + loff0 + j * (32 * RG_KC * 2)) = G[P][j]
+        // ---- weight fragments of this wave: row tile w, k-step g = 8 c + ks at (w tile stride + g 512 + 8 lane) elements.  A ring of
+        // WR fragments: fragment g + WR is fetched right behind the MFMAs that were the last to read fragment g (WR k-steps = ~0.6 us
+        // ahead of its first use: an L2 hit)
+        constexpr int WR = 4, NG = 8 * NCH;
         const __bf16 *const wp = A.w + (size_t)w * A.w_tile_stride + lane * 8;
-        bf16x8 W[8];
+        bf16x8 W[WR];
         // B fragment of k-step ks, block b: row 32 b + r of the stage, piece (2 ks + h) ^ (r & 15) = 2 ks ^ (h ^ (r & 15))
         const uint32_t brow = (uint32_t)(r * (RG_KC * 2)), bx = (uint32_t)((h ^ (r & 15)) << 4);
 
         f32x16 acc[RG_NB];
         RG_GLOAD(0, 0);
-        if (n_chunks > 1) { RG_GLOAD(1, 1); }
+        if constexpr (NCH > 1) { RG_GLOAD(1, 1); }
+        if constexpr (NCH > 2) { RG_GLOAD(2, 2); }
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) W[ks] = *reinterpret_cast<const bf16x8 *>(wp + (size_t)ks * 512);
+        for (int g = 0; g < WR; ++g) W[g] = *reinterpret_cast<const bf16x8 *>(wp + (size_t)g * 512);
         lds_barrier();  // every wave is done with the previous tile's LDS (and bias_l is visible)
 #pragma unroll
         for (int b = 0; b < RG_NB; ++b) acc[b] = bias_tile(bias_l, 32 * w, h);  // the bias enters through the accumulators (backward: zeros)
-        RG_LSTORE(0);
+        RG_LSTORE(0, 0);
         lds_barrier();
 
-        // one K-chunk (parity P = c & 1): before its MFMAs the loads of chunk c + 2 (into the registers chunk c came through; GPRE), after
-        // every k-step's MFMAs the weight fragment of the next chunk (WPRE); after all of them chunk c + 1 goes from its registers into
-        // the other stage.  GPRE / WPRE are COMPILE-TIME flags and the MFMAs are unconditional (a partial tile multiplies its clamped rows
-        // too): with run-time conditions around the loads or the MFMAs the compiler's wait-count pass loses track at every join and
-        // puts `s_waitcnt vmcnt(0)` in front of every MFMA, i.e. the whole prefetch waits for memory 40 times per chunk (first version of
-        // this kernel: 4.3 us per chunk instead of 1.3).
-#define RG_FRAG(st, s_) \
-    *reinterpret_cast<const bf16x8 *>((st) + brow + ((32u * ((s_) / RG_NB)) ^ bx) + ((s_) % RG_NB) * (32 * RG_KC * 2))
-#define RG_CHUNK(P, c, GPRE, WPRE)                                                                                         \
-    {                                                                                                                      \
-        if (GPRE) { RG_GLOAD(P, (c) + 2); }                                                                                \
-        const char *const st = smem + (P) * RG_STAGE;                                                                      \
-        constexpr int PRE = RG_NB, NS = 8 * RG_NB; /* step s: k-step s / 5, block s % 5; B fragments one k-step ahead */   \
-        bf16x8 q[PRE];                                                                                                     \
-        _Pragma("unroll") for (int s_ = 0; s_ < PRE; ++s_) q[s_] = RG_FRAG(st, s_);                                        \
-        _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {                                                                \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            const int ks = s_ / RG_NB, b = s_ % RG_NB;                                                                     \
-            acc[b] = mfma(W[ks], q[s_ % PRE], acc[b]);                                                                     \
-            if (s_ + PRE < NS) q[s_ % PRE] = RG_FRAG(st, s_ + PRE);                                                        \
-            if (WPRE && b == RG_NB - 1) W[ks] = *reinterpret_cast<const bf16x8 *>(wp + (size_t)(8 * ((c) + 1) + ks) * 512); \
-        }                                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        if (WPRE) { RG_LSTORE((P) ^ 1); }                                                                                  \
-        lds_barrier();                                                                                                     \
-    }
-        // ---- epilogue state, declared in front of the LAST K-chunk: wave w takes rows w, w + 8, ... of the tile; lane l holds features
+        // ---- epilogue state, declared in front of the K-loop (its first loads are issued inside the last chunk): wave w takes rows w, w + 8, ... of the tile; lane l holds features
         // 4 l .. 4 l + 3 of a row.  The residual rows of the first batch are requested under the last chunk's MFMAs (the registers of
         // the X prefetch are free by then), the rest right after the output tile is staged.  Rows past the tile are computed on the
         // tile's last row and not stored - no control flow inside a batch.
@@ -228,17 +209,39 @@ k_rowgemm(RowGemmArgs A) {
         using I0 = std::integral_constant<int, 0>;
         using IB = std::integral_constant<int, RG_BATCH>;
         using IR = std::integral_constant<int, RG_RPW>;
-        // (K is a multiple of 256: chunks come in pairs; the last pair is peeled: nothing left to prefetch)
-        for (int c = 0; c + 2 < n_chunks; c += 2) {
-            RG_CHUNK(0, c, 1, 1);
-            RG_CHUNK(1, c + 1, 1, 1);
-        }
-        RG_CHUNK(0, n_chunks - 2, 0, 1);
-        if (PIPE) {  // (under the last chunk's MFMAs)
-            if (MODE == RG_FWD) fwd_load(I0{}, IB{});
-            else bwd_load(0, I0{});
-        }
-        RG_CHUNK(1, n_chunks - 1, 0, 0);
+        // one K-chunk c (a compile-time constant): before its MFMAs the loads of chunk c + 3 (into the registers chunk c came through),
+        // after every k-step's MFMAs the weight fragment WR k-steps ahead; after all of them chunk c + 1 goes from its registers into
+        // the other stage.  Everything conditional is `if constexpr`, and the MFMAs are unconditional (a partial tile multiplies its
+        // clamped rows too): with run-time conditions around the loads or the MFMAs the compiler's wait-count pass loses track at every
+        // join and puts `s_waitcnt vmcnt(0)` in front of every MFMA, i.e. the whole prefetch waits for memory 40 times per chunk (first
+        // version of this kernel: 4.3 us per chunk).
+#define RG_FRAG(st, s_) \
+    *reinterpret_cast<const bf16x8 *>((st) + brow + ((32u * ((s_) / RG_NB)) ^ bx) + ((s_) % RG_NB) * (32 * RG_KC * 2))
+#define RG_CHUNK(c)                                                                                                        \
+    if constexpr ((c) < NCH) {                                                                                             \
+        if constexpr ((c) == NCH - 1 && PIPE) { /* the first batch of residual rows, under the last chunk's MFMAs */       \
+            if (MODE == RG_FWD) fwd_load(I0{}, IB{});                                                                      \
+            else bwd_load(0, I0{});                                                                                        \
+        }                                                                                                                  \
+        if constexpr ((c) + 3 < NCH) { RG_GLOAD((c) % 3, 3); }                                                             \
+        const char *const st = smem + ((c) & 1) * RG_STAGE;                                                                \
+        constexpr int PRE = 3, NS = 8 * RG_NB; /* step s: k-step s / NB, block s % NB; B fragments three MFMAs ahead */    \
+        bf16x8 q[PRE];                                                                                                     \
+        _Pragma("unroll") for (int s_ = 0; s_ < PRE; ++s_) q[s_] = RG_FRAG(st, s_);                                        \
+        _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            const int ks = s_ / RG_NB, b = s_ % RG_NB, g = 8 * (c) + ks;                                                   \
+            acc[b] = mfma(W[g % WR], q[s_ % PRE], acc[b]);                                                                 \
+            if (s_ + PRE < NS) q[s_ % PRE] = RG_FRAG(st, s_ + PRE);                                                        \
+            if (b == RG_NB - 1 && g + WR < NG) W[g % WR] = *reinterpret_cast<const bf16x8 *>(wp + (size_t)(kc * 8 + ks + WR) * 512); \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        if constexpr ((c) + 1 < NCH) { RG_LSTORE(((c) + 1) % 3, ((c) + 1) & 1); }                                          \
+        kc += 1;                                                                                                           \
+        asm volatile("" : "+s"(kc));                                                                                       \
+        lds_barrier();                                                                                                     \
+    }
+        RG_CHUNK(0) RG_CHUNK(1) RG_CHUNK(2) RG_CHUNK(3) RG_CHUNK(4) RG_CHUNK(5) RG_CHUNK(6) RG_CHUNK(7)
 #undef RG_CHUNK
 #undef RG_FRAG
 #undef RG_GLOAD
@@ -440,22 +443,35 @@ inline int rg_tpw(int64_t T, int *nb) {
     return (int)(t > 160 ? 160 : t);
 }
 
+template <int MODE, int NB, int NCH>
+int rg_launch3(RowGemmArgs &A, unsigned grid, hipStream_t stream) {
+    const void *fn = reinterpret_cast<const void *>(k_rowgemm<MODE, NB, NCH>);
+    constexpr int lds = RgShape<NB>::LDS;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -(1000 + (int)hipGetLastError());
+    hipLaunchKernelGGL((k_rowgemm<MODE, NB, NCH>), dim3(grid), dim3(RG_THREADS), lds, stream, A);
+    return rg_done();
+}
+template <int MODE, int NB>
+int rg_launch2(RowGemmArgs &A, unsigned grid, hipStream_t stream) {
+    switch (A.K / RG_KC) {  // the K-loop is unrolled over its chunks: K = 256, 512, 768, 1024
+        case 2: return rg_launch3<MODE, NB, 2>(A, grid, stream);
+        case 4: return rg_launch3<MODE, NB, 4>(A, grid, stream);
+        case 6: return rg_launch3<MODE, NB, 6>(A, grid, stream);
+        case 8: return rg_launch3<MODE, NB, 8>(A, grid, stream);
+        default: return G2048_EINVAL;
+    }
+}
 template <int MODE>
 int rg_launch(RowGemmArgs &A, hipStream_t stream) {
     int nb = 5;
     A.tpw = rg_tpw(A.T, &nb);
     const int64_t tiles = (A.T + A.tpw - 1) / A.tpw;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    const void *fn = nb == 3 ? reinterpret_cast<const void *>(k_rowgemm<MODE, 3>) : reinterpret_cast<const void *>(k_rowgemm<MODE, 5>);
-    const int lds = nb == 3 ? RgShape<3>::LDS : RgShape<5>::LDS;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -(1000 + (int)hipGetLastError());
-    if (nb == 3) hipLaunchKernelGGL((k_rowgemm<MODE, 3>), dim3(grid), dim3(RG_THREADS), lds, stream, A);
-    else hipLaunchKernelGGL((k_rowgemm<MODE, 5>), dim3(grid), dim3(RG_THREADS), lds, stream, A);
-    return rg_done();
+    return nb == 3 ? rg_launch2<MODE, 3>(A, grid, stream) : rg_launch2<MODE, 5>(A, grid, stream);
 }
 
 inline bool rg_gemm_ok(const void *x, int64_t ldx, const void *w, int64_t T, int K) {
-    return x && w && T > 0 && K >= 256 && K % 256 == 0 && K <= 4096 && ldx >= K && !(ldx & 7) && !(((uintptr_t)x | (uintptr_t)w) & 15) &&
+    return x && w && T > 0 && K >= 256 && K % 256 == 0 && K <= 1024 && ldx >= K && !(ldx & 7) && !(((uintptr_t)x | (uintptr_t)w) & 15) &&
            (int64_t)160 * ldx * 2 < (1ll << 31);
 }
 

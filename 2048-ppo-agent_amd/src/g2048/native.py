@@ -73,6 +73,11 @@ SIGNATURES = {
     "g2048_linear_add_ln_bwd_partial_rows": [_i64],
     "g2048_linear_add_ln_bwd": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                 C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_mlp_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "g2048_gemm_jobs": [_vp, _i32, _i64, _vp],
+    "g2048_mlp_out_fwd": [_vp, _vp, _vp, _vp, _i64, _vp],
+    "g2048_mlp_out_bwd_partial_rows": [_i64],
+    "g2048_mlp_out_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "g2048_add_ln_bwd_workspace_floats": [_i64],
     "g2048_add_ln_bwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp,
                          _i32, _vp],
@@ -110,7 +115,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
             fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_workspace_bytes", "_partial_rows", "_mask_bytes")) else C.c_int
-        if lib.g2048_abi_version() != 2:
+        if lib.g2048_abi_version() != 3:
             raise NativeError("libg2048.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -384,7 +389,7 @@ def rowgemm_ok(u2: torch.Tensor, w_packed: torch.Tensor, tile_stride: int = 0) -
         return False
     T, K = u2.shape
     span = 256 * K if not tile_stride else 7 * int(tile_stride) + (K // 16) * 512
-    return (T > 0 and K % 256 == 0 and 256 <= K <= 4096 and u2.stride(0) >= K and u2.stride(0) % 8 == 0 and u2.data_ptr() % 16 == 0
+    return (T > 0 and K % 256 == 0 and 256 <= K <= 1024 and u2.stride(0) >= K and u2.stride(0) % 8 == 0 and u2.data_ptr() % 16 == 0
             and w_packed is not None and w_packed.is_cuda and w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
             and (w_packed.numel() == span if not tile_stride else (w_packed.numel() >= span and tile_stride >= (K // 16) * 512
                                                                   and tile_stride % 8 == 0))
@@ -424,6 +429,81 @@ def linear_add_ln_bwd(dy2, wt_packed, xn_ptr: int, x_row_stride: int, g_x, mean,
                                           int(extra_period), _dev(mean, f32, T, "mean"), _dev(rstd, f32, T, "rstd"), _dev(gamma, f32, 256, "gamma"),
                                           _dev(dx, f32, 256 * T, "dx"), _dev(da, bf, 256 * T, "da", optional=True), ws.data_ptr(), T,
                                           float(p_drop), int(seed), seed_state or None, _stream()), "g2048_linear_add_ln_bwd")
+    return ws
+
+
+# ---- MLP policy (configs[1]): csrc/g2048_mlp.hip ---------------------------------------------------------------------------------
+GEMM_MAX_JOBS = 8
+
+
+class GemmJob(C.Structure):
+    _fields_ = [("x", _vp * 2), ("ldx", _i64 * 2), ("w", _vp * 2), ("ldw", _i64 * 2), ("k", _i32 * 2), ("bias", _vp), ("act", _vp),
+                ("ldact", _i64), ("y", _vp), ("ldy", _i64), ("N", _i32), ("relu", _i32)]
+
+
+def _bf16_rows(t: torch.Tensor, name: str):
+    if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16:
+        raise NativeError(f"{name}: expected a bf16 [rows, cols] device tensor with unit column stride, 16-byte aligned rows; got "
+                          f"{tuple(t.shape)} {t.dtype} strides {t.stride()}")
+    return t.data_ptr(), t.stride(0)
+
+
+def gemm_jobs(jobs, M: int):
+    """``g2048_gemm_jobs``: jobs = list of dicts ``segs`` [(x [M, k] bf16, w [N, k] bf16), ...] (one or two), ``y`` [M, N] bf16, optional
+    ``bias`` f32 [N], ``relu`` bool, ``act`` bf16 [M, N] (the output is multiplied by (act > 0)).  Column-slice views are fine."""
+    recs = []
+    for q in jobs:
+        segs = q["segs"]
+        if not 1 <= len(segs) <= 2:
+            raise NativeError("gemm_jobs: one or two K-segments per job")
+        y = q["y"]
+        yp, ldy = _bf16_rows(y, "y")
+        N = y.shape[1]
+        xs, ldxs, ws, ldws, ks = [0, 0], [0, 0], [0, 0], [0, 0], [0, 0]
+        for i, (x, w) in enumerate(segs):
+            xs[i], ldxs[i] = _bf16_rows(x, "x")
+            ws[i], ldws[i] = _bf16_rows(w, "w")
+            ks[i] = x.shape[1]
+            if x.shape[0] != M or y.shape[0] != M or w.shape != (N, ks[i]) or ks[i] % 64 or N % 64:
+                raise NativeError(f"gemm_jobs: shapes x {tuple(x.shape)} w {tuple(w.shape)} y {tuple(y.shape)} (M = {M})")
+        act = q.get("act")
+        ap, lda = (0, 0) if act is None else _bf16_rows(act, "act")
+        if act is not None and tuple(act.shape) != (M, N):
+            raise NativeError("gemm_jobs: act must be [M, N]")
+        bias = q.get("bias")
+        recs.append(GemmJob((_vp * 2)(*xs), (_i64 * 2)(*ldxs), (_vp * 2)(*ws), (_i64 * 2)(*ldws), (_i32 * 2)(*ks),
+                            None if bias is None else _dev(bias, f32, N, "bias"), ap or None, lda, yp, ldy, N, int(bool(q.get("relu")))))
+    if not 1 <= len(recs) <= GEMM_MAX_JOBS:
+        raise NativeError(f"gemm_jobs: 1..{GEMM_MAX_JOBS} jobs per launch")
+    arr = (GemmJob * len(recs))(*recs)
+    _check(load().g2048_gemm_jobs(C.cast(arr, _vp), len(recs), int(M), _stream()), "g2048_gemm_jobs")
+
+
+def mlp_embed_fwd(boards, wt, bias, y, onehot=None):
+    """y[M, 512] (bf16) = relu(bias + sum of the 16 selected rows of wt [496, 512] (bf16, the transposed trunk_in weight)); ``onehot``
+    (bf16 [M, 512]) receives the one-hot matrix."""
+    M = boards.shape[0]
+    bf = torch.bfloat16
+    _check(load().g2048_mlp_embed_fwd(_dev(boards, u8, 16 * M, "boards"), _dev(wt, bf, 496 * 512, "wt"), _dev(bias, f32, 512, "bias"),
+                                      _dev(y, bf, 512 * M, "y"), _dev(onehot, bf, 512 * M, "onehot", optional=True), M, _stream()),
+           "g2048_mlp_embed_fwd")
+
+
+def mlp_out_fwd(h2, w3, logits, values):
+    M = h2.shape[0]
+    bf = torch.bfloat16
+    _check(load().g2048_mlp_out_fwd(_dev(h2, bf, 1024 * M, "h2"), _dev(w3, bf, 5 * 512, "w3"), _dev(logits, f32, 4 * M, "logits"),
+                                    _dev(values, f32, M, "values"), M, _stream()), "g2048_mlp_out_fwd")
+
+
+def mlp_out_bwd(dlogits, dvalues, h2, w3, dh2):
+    """-> partial f32 [rows, 5, 512]: first-stage sums of the output layers' weight gradients."""
+    M = h2.shape[0]
+    bf = torch.bfloat16
+    ws = torch.empty((int(load().g2048_mlp_out_bwd_partial_rows(M)), 5, 512), dtype=f32, device=h2.device)
+    _check(load().g2048_mlp_out_bwd(_dev(dlogits, f32, 4 * M, "dlogits"), _dev(dvalues, f32, M, "dvalues"), _dev(h2, bf, 1024 * M, "h2"),
+                                    _dev(w3, bf, 5 * 512, "w3"), _dev(dh2, bf, 1024 * M, "dh2"), ws.data_ptr(), M, _stream()),
+           "g2048_mlp_out_bwd")
     return ws
 
 

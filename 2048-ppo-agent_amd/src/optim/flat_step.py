@@ -106,6 +106,12 @@ class FlatAdamWStep:
         for sh in shadows:
             if sh in self._shadows or getattr(sh, "views", None) is None or not all(id(p) in mine for p in sh.params):
                 continue
+            # ONE maintained shadow per parameter: the chunk table holds one set of shadow pointers per parameter, so a second shadow
+            # over a parameter that an adopted one already covers would be marked maintained and never rewritten (stale weights in
+            # whatever reads it).  It stays un-adopted instead and keeps refreshing itself by copy when its key is stale.
+            taken = {id(p) for other in self._shadows for p in other.params}
+            if any(id(p) in taken for p in sh.params):
+                continue
             sh.key = None
             sh()  # one eager refresh: from here on the kernel writes the same values in place
             sh.maintainer = self

@@ -200,9 +200,24 @@ class MLPAgent(_ActorCritic):
         self.actor = _head(trunk_dim, hidden_dim, action_dim)
         self.critic = _head(trunk_dim, hidden_dim, 1)
 
+    def _plan(self):
+        """The ``MLPPlan`` of the standard shapes (None otherwise): ONE bf16 shadow of all fourteen parameters, which both the
+        ten-launch update node and the bf16 rollout forward read - two shadows over the same parameter cannot both be kept
+        current by the optimiser kernel (``FlatAdamWStep.adopt_shadows``)."""
+        from .mlp_ops import MLPPlan
+
+        if self._mlp_plan is None and MLPPlan.supports(self):
+            self._mlp_plan = MLPPlan(self)
+        return self._mlp_plan
+
     def _shadows(self):
         """(trunk views, head views) of the bf16 weight shadows (created on first use; the optimiser kernel keeps them current
         once it has adopted them, otherwise they re-copy when a parameter's version moved)."""
+        plan = self._plan() if next(self.parameters()).is_cuda else None
+        if plan is not None:
+            d = plan.views()[0]
+            return ([d[k] for k in ("win", "bin", "wh", "bh")],
+                    [d[k] for k in ("a1w", "a1b", "a2w", "a2b", "a3w", "c1w", "c1b", "c2w", "c2b", "c3w")])
         if self._trunk_shadow is None:
             self._trunk_shadow = Bf16Shadow([self.trunk_in.weight, self.trunk_in.bias, self.trunk_hidden.weight,
                                              self.trunk_hidden.bias])
@@ -222,12 +237,43 @@ class MLPAgent(_ActorCritic):
                 and not torch.is_grad_enabled() and torch.is_autocast_enabled()
                 and torch.get_autocast_dtype("cuda") == torch.bfloat16 and self.trunk_in.weight.dtype == torch.float32)
 
+    _mlp_plan = None
+
+    def _update_node_ok(self, observations) -> bool:
+        """The update path on packed boards at the standard shapes: the whole policy is one autograd node over ten launches
+        (``mlp_ops._MLPUpdate``; G2048_MLP_FUSED=0 keeps the per-layer nodes, the A/B switch)."""
+        import os
+
+        from .mlp_ops import MLPPlan
+
+        return (observations.dtype == torch.uint8 and observations.dim() == 2 and observations.shape[1] == 16
+                and _train_bf16(observations, self.trunk_in.weight) and MLPPlan.supports(self)
+                and os.environ.get("G2048_MLP_FUSED", "1").strip().lower() not in ("0", "false", "no", "off"))
+
     def forward(self, observations: torch.Tensor, action_mask: torch.Tensor = None):
+        if self._update_node_ok(observations):
+            from .mlp_ops import MLPPlan, _MLPUpdate
+
+            plan = self._plan()
+            logits, values = _MLPUpdate.apply(observations, plan, *plan.params)
+            if action_mask is not None:
+                logits = logits - 1e8 * (1 - action_mask.float())
+            return logits, values
         if not self._rollout_bf16_ok(observations):
             return super().forward(observations, action_mask)
         # bf16 rollout inference on packed boards: one-hot GEMM + bias/ReLU epilogues on the pre-cast shadows, 12 launches per
         # lock-step instead of 42 (the f32 gather-sum of the generic path alone is 130 us at 4 096 boards); same arithmetic
         # as the update's autocast forward (bf16 operands, f32 accumulation, bf16 activations)
+        plan = self._plan()
+        if plan is not None and observations.shape[1] == 16:
+            # the standard shapes: the five launches of the update node's forward (trunk_in as a gather-sum on the packed boards, job
+            # tables for the layers); while being captured the shadows are read as they are (see the other branch)
+            from .mlp_ops import forward_nograd
+
+            logits, values = forward_nograd(observations, plan, refresh=not torch.cuda.is_current_stream_capturing())
+            if action_mask is not None:
+                logits = logits - 1e8 * (1 - action_mask.float())
+            return logits, values
         ts, hs = self._trunk_shadow, self._head_shadow
         if torch.cuda.is_current_stream_capturing() and ts is not None and hs is not None and ts.views is not None \
                 and hs.views is not None:

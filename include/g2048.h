@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 2
+#define G2048_ABI_VERSION 3
 #define G2048_EINVAL (-1)
 #define G2048_RNG_LEGACY 0
 #define G2048_RNG_PARTITIONABLE 1
@@ -235,7 +235,7 @@ int g2048_add_ln_bwd(const float *x_norm, int64_t x_row_stride, const float *g_x
  * followed by g2048_add_ln_fwd, without the bf16 [T][256] tensor between them (reference: `x = x + dropout1(self_attn(...))` /
  * `x = x + dropout2(linear2(...))` + the next sub-layer's norm, nn.TransformerEncoderLayer(norm_first=True) built at
  * src/ppo/transformer_encoder.py:138-148).  u bf16 [T][K], leading dimension ldu (elements, multiple of 8); w_packed: the Linear's
- * weight [256][K] as bf16 in the FRAGMENT-PACKED layout above (g2048_opt_step maintains such copies); K a multiple of 256; bias f32 [256]
+ * weight [256][K] as bf16 in the FRAGMENT-PACKED layout above (g2048_opt_step maintains such copies); K = 256, 512, 768 or 1024; bias f32 [256]
  * or NULL; the rest as g2048_add_ln_fwd (same dropout hash on the same element index: the two paths draw the same mask for the same
  * seed).  The Linear's output is rounded to bf16 before dropout and the add, as the unfused pair does. */
 int g2048_linear_add_ln_fwd(const void *u, int64_t ldu, const void *w_packed, const float *bias, int K, const float *x,
@@ -254,6 +254,42 @@ int g2048_linear_add_ln_bwd(const void *dy, int64_t lddy, const void *wt_packed,
                             int64_t x_row_stride, const float *g_x, int g_x_period, const void *g_h_extra, int extra_period,
                             const float *mean, const float *rstd, const float *gamma, float *dx, void *da, float *partial, int64_t T,
                             float p_drop, uint64_t seed, const uint64_t *seed_state, void *stream);
+
+/* ---- MLP policy (BASELINE configs[1]): the update as a handful of launches ---------------------------------------------- */
+
+/* trunk_in on packed boards: y[m] = relu(bias + sum over the 16 cells c of wt[31 c + boards[m][c]]) (bf16 [M][512]) - a one-hot input
+ * times W^T is a sum of weight columns (reference: the MLP policy has no counterpart in the reference; its input convention is the
+ * one-hot observation of src/runs/batch_runner.py:130-136).  wt: bf16 [496][512], the TRANSPOSE of the Linear's weight [512][496];
+ * bias f32 [512]; onehot (bf16 [M][512], columns 496.. zero; may be NULL): the one-hot matrix itself, which the weight-gradient launch
+ * multiplies with. */
+int g2048_mlp_embed_fwd(const uint8_t *boards, const void *wt, const float *bias, void *y, void *onehot, int64_t M, void *stream);
+
+/* A table of small GEMMs in ONE launch: for every job y[M][N] (bf16) = epi(sum over its K-segments s of x[s][M][k[s]] . w[s][N][k[s]]^T),
+ * bf16 operands, f32 accumulation; epi: + bias (f32 [N], or NULL), ReLU when relu != 0, multiplied by (act > 0) when act (bf16 [M][N],
+ * leading dimension ldact) is given - the ReLU backward on a saved activation.  Two K-segments: two Linears back-propagating into the
+ * same input.  Replaces nn.Linear + ReLU and their autograd for 2048-row activations, where a hipGraph node costs more than its
+ * arithmetic.  N, k[s] multiples of 64 (k[1] may be 0); leading dimensions multiples of 8 (ldact: 4); bases 16-byte aligned (act: 8).
+ * jobs: host array, read during the call. */
+#define G2048_GEMM_MAX_JOBS 8
+typedef struct {
+    const void *x[2]; int64_t ldx[2];
+    const void *w[2]; int64_t ldw[2];
+    int32_t k[2];
+    const float *bias;
+    const void *act; int64_t ldact;
+    void *y; int64_t ldy;
+    int32_t N, relu;
+} g2048_gemm_job;
+int g2048_gemm_jobs(const g2048_gemm_job *jobs, int n_jobs, int64_t M, void *stream);
+
+/* Both heads' output layers: logits[m][0..3] = h2[m][:512] . w3[0..3]^T, values[m] = h2[m][512:] . w3[4]  (h2 bf16 [M][1024] = the
+ * actor's | the critic's last hidden layer; w3 bf16 [5][512] = actor.4.weight, then critic.4.weight: src/ppo/ppo_agent.py:72-87). */
+int g2048_mlp_out_fwd(const void *h2, const void *w3, float *logits, float *values, int64_t M, void *stream);
+/* Their backward: dh2 (bf16 [M][1024]) = [w3[0..3]^T dlogits | w3[4] dvalues] where h2 > 0; partial: f32
+ * [g2048_mlp_out_bwd_partial_rows(M)][5][512] first-stage sums of the output layers' weight gradients (for g2048_reduce_jobs). */
+int64_t g2048_mlp_out_bwd_partial_rows(int64_t M);
+int g2048_mlp_out_bwd(const float *dlogits, const float *dvalues, const void *h2, const void *w3, void *dh2, float *partial, int64_t M,
+                      void *stream);
 
 /* ---- policy network (update): bias gradients ------------------------------------------------------------ */
 

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/g2048.h but not exported"
     assert sorted(nv.SIGNATURES) == names  # the ctypes binding covers exactly the header
-    assert nv.load().g2048_abi_version() == 2
+    assert nv.load().g2048_abi_version() == 3
 
 
 @pytest.mark.parametrize("mode", [0, 1])
