@@ -6,7 +6,7 @@
 // workgroup would stream all 3.1 MB of weights through one CU's memory path (>= 50 us per pass: the fused CLS tail's floor) - so the
 // layers stay separate launches, but each launch does everything that belongs to its layer:
 //   k_mlp_embed_fwd   trunk_in on packed boards: one-hot x W^T is a sum of 16 weight columns; + bias + ReLU; also leaves the one-hot
-//                     matrix (bf16 [M][512]) that the grouped weight-gradient launch multiplies with
+//                     matrix (bf16 [M][512], a column of ones at 496) that the grouped weight-gradient launch multiplies with
 //   k_gemm_jobs       a table of small GEMMs per launch, y = epi(sum_s x_s . w_s^T): up to two K-segments per job (the actor's and the
 //                     critic's first layers back-propagate into the SAME trunk gradient), bias + ReLU (forward) or the ReLU mask of a
 //                     saved activation (backward) in the epilogue, several jobs per launch (the two heads' layers side by side)
@@ -72,8 +72,9 @@ k_mlp_embed_fwd(const uint8_t *__restrict__ boards, const uint16_t *__restrict__
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = f2bf(fmaxf(acc[2 * q], 0.f)) | (f2bf(fmaxf(acc[2 * q + 1], 0.f)) << 16);
     reinterpret_cast<uint4 *>(y + row * ME_D)[lane] = make_uint4(o[0], o[1], o[2], o[3]);
-    if (onehot) {  // elements 8 lane .. 8 lane + 7 of the row's one-hot vector (columns 496.. stay zero)
-        uint32_t h[4] = {0u, 0u, 0u, 0u};
+    if (onehot) {  // elements 8 lane .. 8 lane + 7 of the row's one-hot vector; column 496 = 1 (onehot^T dY then carries the column sums
+                   // of dY = trunk_in's bias gradient in its row 496), columns 497.. stay zero
+        uint32_t h[4] = {lane == (ME_CELLS * ME_CLASSES) / 8 ? 0x3F80u : 0u, 0u, 0u, 0u};
 #pragma unroll
         for (int c = 0; c < ME_CELLS; ++c)
             if ((idx[c] >> 3) == lane) h[(idx[c] & 7) >> 1] |= 0x3F80u << (16 * (idx[c] & 1));  // bf16 1.0
@@ -84,7 +85,11 @@ k_mlp_embed_fwd(const uint8_t *__restrict__ boards, const uint16_t *__restrict__
 // ---- a table of small GEMMs ------------------------------------------------------------------------------------------------
 // Workgroup (4 waves) = one [64 rows x 64 outputs] tile of one job; computed transposed (Y^T = W X^T: the weight tile is the A operand
 // in nn.Linear's [N][K] layout, rows sit on lanes); K in chunks of 64 through two LDS stages (register staging: everything visible to
-// the compiler's wait counts); the output tile leaves through LDS as full 128-byte row segments.
+// the compiler's wait counts); the output tile leaves through LDS as full 128-byte row segments.  32 KB of LDS: four or five workgroups
+// share a CU and hide each other's round trips.  (Measured and dropped, round 4: the whole K extent of both tiles requested at once by
+// LDS-DMA, one wait, one barrier - 128 KB of LDS, one workgroup per CU: 57.8 instead of 52.8 us for the six launches of a minibatch.  What
+// a launch costs is the 128 KB every 64 x 64 tile pulls through its CU's memory path, and co-resident small workgroups keep that path
+// busier than one large one.)
 constexpr int GJ_TM = 64, GJ_TN = 64, GJ_KC = 64, GJ_THREADS = 256;
 constexpr int GJ_TILE = GJ_TM * GJ_KC * 2;  // 8 KB: one operand tile, rows of 128 bytes, 16-byte piece p of row r at p ^ ((r >> 1) & 7)
 // ((r >> 1): two consecutive 128-byte rows fill the 64 banks once, so rows r and r + 2 must not share a piece slot)
@@ -224,37 +229,47 @@ k_mlp_out_fwd(const uint16_t *__restrict__ h2, const uint16_t *__restrict__ w3, 
 }
 
 // d h2 = [W_a3^T d logits | W_c3^T d value] where h2 > 0 (bf16 [M][1024]), and this workgroup's share of the output layers' weight
-// gradients: partial[blockIdx][5][512] f32 = sum over its 32 rows of d out[row][o] * h2[row][half(o)][:]  (fixed order; summed by
-// g2048_reduce_jobs).  Thread t owns columns t and t + 256 of each 512-wide half.
-constexpr int MO_ROWS = 32;
+// gradients: partial[blockIdx][5][512] f32 = sum over its 8 rows of d out[row][o] * h2[row][half(o)][:]  (fixed order; summed by
+// g2048_reduce_jobs).  Thread t owns columns 2t, 2t + 1 of each 512-wide half (4-byte loads and stores, 256 contiguous bytes per wave);
+// 8 rows per workgroup = 256 workgroups at minibatch 2048 (32 rows: 64 workgroups, 13 us of serial 2-byte accesses - now ~6).
+constexpr int MO_ROWS = 8;
 
 __global__ void __launch_bounds__(256)
 k_mlp_out_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalues, const uint16_t *__restrict__ h2,
               const uint16_t *__restrict__ w3, uint16_t *__restrict__ dh2, float *__restrict__ partial, int64_t M) {
     __shared__ float dl[MO_ROWS][5];
     const int64_t r0 = (int64_t)blockIdx.x * MO_ROWS;
-    for (int i = threadIdx.x; i < MO_ROWS * 5; i += 256) {
-        const int rr = i / 5, o = i % 5;
+    const int t = threadIdx.x;
+    uint32_t hq[MO_ROWS][2];  // this thread's pair of columns of every row, both halves: all loads in flight before the first use
+#pragma unroll
+    for (int rr = 0; rr < MO_ROWS; ++rr) {
+        const int64_t row = r0 + rr < M ? r0 + rr : M - 1;
+        const uint32_t *hr = reinterpret_cast<const uint32_t *>(h2 + row * (2 * MO_H));
+        hq[rr][0] = hr[t];
+        hq[rr][1] = hr[MO_H / 2 + t];
+    }
+    if (t < MO_ROWS * 5) {
+        const int rr = t / 5, o = t % 5;
         const int64_t row = r0 + rr;
         // (rounded to bf16, as the unfused path hands the gradients to its bf16 GEMMs)
         dl[rr][o] = row < M ? bf2f(f2bf(o < 4 ? dlogits[row * 4 + o] : dvalues[row])) : 0.f;
     }
+    float wv[2][5], pw[2][5];  // [column of the pair][output]
+#pragma unroll
+    for (int o = 0; o < 5; ++o) {
+        const uint32_t w = reinterpret_cast<const uint32_t *>(w3 + o * MO_H)[t];
+        wv[0][o] = bf2f(w & 0xFFFFu), wv[1][o] = bf2f(w >> 16);
+        pw[0][o] = pw[1][o] = 0.f;
+    }
     __syncthreads();
-    float wv[2][5], pw[2][5];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int o = 0; o < 5; ++o) {
-            wv[c][o] = bf2f(w3[o * MO_H + threadIdx.x + 256 * c]);
-            pw[c][o] = 0.f;
-        }
-    for (int rr = 0; rr < MO_ROWS; ++rr) {
+    for (int rr = 0; rr < MO_ROWS; ++rr) {  // ascending rows: a fixed summation order
         const int64_t row = r0 + rr;
         if (row >= M) break;
+        uint32_t oa = 0u, oc = 0u;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int col = threadIdx.x + 256 * c;
-            const uint16_t ha = h2[row * (2 * MO_H) + col], hc = h2[row * (2 * MO_H) + MO_H + col];
+            const uint32_t ha = (hq[rr][0] >> (16 * c)) & 0xFFFFu, hc = (hq[rr][1] >> (16 * c)) & 0xFFFFu;
             const float fa = bf2f(ha), fc = bf2f(hc);
             float ga = 0.f;
 #pragma unroll
@@ -263,14 +278,16 @@ k_mlp_out_bwd(const float *__restrict__ dlogits, const float *__restrict__ dvalu
                 pw[c][o] = __builtin_fmaf(dl[rr][o], fa, pw[c][o]);
             }
             pw[c][4] = __builtin_fmaf(dl[rr][4], fc, pw[c][4]);
-            dh2[row * (2 * MO_H) + col] = (uint16_t)((ha & 0x7FFFu) ? f2bf(ga) : 0u);
-            dh2[row * (2 * MO_H) + MO_H + col] = (uint16_t)((hc & 0x7FFFu) ? f2bf(dl[rr][4] * wv[c][4]) : 0u);
+            oa |= ((ha & 0x7FFFu) ? f2bf(ga) : 0u) << (16 * c);
+            oc |= ((hc & 0x7FFFu) ? f2bf(dl[rr][4] * wv[c][4]) : 0u) << (16 * c);
         }
+        uint32_t *dr = reinterpret_cast<uint32_t *>(dh2 + row * (2 * MO_H));
+        dr[t] = oa;
+        dr[MO_H / 2 + t] = oc;
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int o = 0; o < 5; ++o) partial[((int64_t)blockIdx.x * 5 + o) * MO_H + threadIdx.x + 256 * c] = pw[c][o];
+    for (int o = 0; o < 5; ++o)
+        reinterpret_cast<float2 *>(partial + ((int64_t)blockIdx.x * 5 + o) * MO_H)[t] = make_float2(pw[0][o], pw[1][o]);
 }
 
 }  // namespace
@@ -320,7 +337,7 @@ extern "C" int64_t g2048_mlp_out_bwd_partial_rows(int64_t M) { return M <= 0 ? 0
 
 extern "C" int g2048_mlp_out_bwd(const float *dlogits, const float *dvalues, const void *h2, const void *w3, void *dh2, float *partial,
                                  int64_t M, void *stream) {
-    if (!dlogits || !dvalues || !h2 || !w3 || !dh2 || !partial || M <= 0 || ((uintptr_t)partial & 3)) return G2048_EINVAL;
+    if (!dlogits || !dvalues || !h2 || !w3 || !dh2 || !partial || M <= 0 || (((uintptr_t)partial | (uintptr_t)h2 | (uintptr_t)w3 | (uintptr_t)dh2) & 7)) return G2048_EINVAL;
     hipLaunchKernelGGL(k_mlp_out_bwd, dim3((unsigned)((M + MO_ROWS - 1) / MO_ROWS)), dim3(256), 0, (hipStream_t)stream, dlogits, dvalues,
                        (const uint16_t *)h2, (const uint16_t *)w3, (uint16_t *)dh2, partial, M);
     return mlp_done();

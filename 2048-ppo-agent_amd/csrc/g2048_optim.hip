@@ -1,4 +1,4 @@
-// The optimiser step of the PPO update in three launches: gradient-norm clipping, GradScaler bookkeeping and AdamW over all
+// The optimiser step of the PPO update in two launches: gradient-norm clipping, GradScaler bookkeeping and AdamW over all
 // parameters at once (reference: src/ppo/ppo_trainer.py:413-434 - scaler.unscale_, clip_grad_norm_, scaler.step(AdamW),
 // scaler.update - which PyTorch runs as ~12 multi-tensor launches per minibatch, 0.25 ms of a 3.2 ms minibatch).
 //
@@ -12,8 +12,8 @@
 //                  g' = (g * inv_scale) * clip;  p -= lr*wd*p;  m = lerp(m, g', 1-b1);  v = b2*v + (1-b2)*g'^2;
 //                  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)                      (torch's fused AdamW arithmetic)
 //                  unless found_inf
-//   k_opt_finish : one workgroup advances the step counts and the scaler (scale *= backoff on inf, *= growth after
-//                  growth_interval clean steps), as scaler.update() does.
+//                  workgroup 0 also advances the step counts and the scaler (scale *= backoff on inf, *= growth after
+//                  growth_interval clean steps, as scaler.update() does): finish()
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -46,7 +46,7 @@ struct StepArgs {
 
 // per-group constants of one step, derived once (by workgroup 0 of k_opt_sqnorm) from the f64 hyper-parameters and the step
 // count: the two f64 pow calls of the bias corrections cost microseconds and must not sit in every workgroup of the update
-struct Derived { float step_size, inv_bc2_sqrt, lr_wd, w1, b2, w2, eps, pad; };
+struct Derived { float step_size, inv_bc2_sqrt, lr_wd, w1, b2, w2, eps, inv_scale; };  // inv_scale: of the scaler BEFORE this step's update
 
 __global__ void __launch_bounds__(OPT_THREADS)
 k_opt_sqnorm(const g2048_opt_chunk *__restrict__ chunks, const float *__restrict__ grads, float *__restrict__ partial, StepArgs A,
@@ -66,7 +66,7 @@ k_opt_sqnorm(const g2048_opt_chunk *__restrict__ chunks, const float *__restrict
         d.b2 = (float)G.beta2;
         d.w2 = (float)(1.0 - G.beta2);
         d.eps = (float)G.eps;
-        d.pad = 0.f;
+        d.inv_scale = scale ? (float)(1.0 / (double)*scale) : 1.f;  // scaler.unscale_: grads *= scale.double().reciprocal().float()
         derived[threadIdx.x] = d;
     }
     const g2048_opt_chunk c = chunks[blockIdx.x];
@@ -153,10 +153,47 @@ __device__ __forceinline__ void refresh_shadow(const g2048_opt_chunk &c, int i, 
     }
 }
 
+// Bookkeeping of one step, by workgroup 0 of k_opt_adamw: step counts, scaler state (scale *= backoff on inf, *= growth after
+// growth_interval clean steps, as scaler.update() does), info.  Nothing of the same launch reads what it writes: the step counts are
+// read by k_opt_sqnorm only, the scale reaches the other workgroups through Derived.inv_scale.  (Rounds 2-3: a launch of its own,
+// k_opt_finish, ~4.5 us of every minibatch.  A "last workgroup done" counter is NOT what this is: that needed a device-scope release
+// fence per workgroup, each writing back its XCD's L2 - measured 114 us for the update kernel instead of 20.)
+struct FinishArgs {
+    float growth, backoff;
+    int growth_interval, n_steps;
+    float *steps;
+    int32_t *growth_tracker;
+    float *info;
+};
+__device__ __forceinline__ void finish(const FinishArgs &F, float total, bool found_inf, float *scale) {
+    if (!found_inf)
+        for (int i = threadIdx.x; i < F.n_steps; i += OPT_THREADS) F.steps[i] += 1.f;  // one count per parameter, as torch keeps them
+    if (threadIdx.x == 0) {
+        if (F.info) {
+            F.info[0] = sqrtf(total);  // gradient norm (unscaled) before clipping: what clip_grad_norm_ returns
+            F.info[1] = found_inf ? 1.f : 0.f;
+        }
+        if (scale) {
+            if (found_inf) {
+                *scale *= F.backoff;
+                *F.growth_tracker = 0;
+            } else {
+                const int32_t ok = *F.growth_tracker + 1;
+                if (ok == F.growth_interval) {
+                    *scale *= F.growth;
+                    *F.growth_tracker = 0;
+                } else {
+                    *F.growth_tracker = ok;
+                }
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(OPT_THREADS)
 k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const float *__restrict__ grads, float *__restrict__ exp_avg,
             float *__restrict__ exp_avg_sq, const float *__restrict__ partial, const Derived *__restrict__ derived, float max_grad_norm,
-            const float *__restrict__ scale) {
+            float *__restrict__ scale, FinishArgs F) {
     __shared__ float lds[OPT_THREADS / 64];
     __shared__ float sh[2];
     __shared__ uint16_t stage[OPT_CHUNK];
@@ -176,8 +213,7 @@ k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const floa
                        (rows_in_chunk == 2 || rows_in_chunk == 4 || rows_in_chunk == 8) && c.rows % rows_in_chunk == 0 &&
                        !(((uintptr_t)c.shadow_t | (uintptr_t)c.shadow_tp) & 15);
     if (threadIdx.x == 0) {
-        const float sc = scale ? *scale : 1.f;
-        const float inv_scale = (float)(1.0 / (double)sc);  // scaler.unscale_: grads *= scale.double().reciprocal().float()
+        const float inv_scale = G.inv_scale;  // (of k_opt_sqnorm's making: workgroup 0 below rewrites *scale while others still start)
         // the norm of the unscaled gradients (k_opt_sqnorm squared g * inv_scale); non-finite anywhere makes the total non-finite
         const float norm = sqrtf(total);
         float clip = 1.f;
@@ -190,6 +226,7 @@ k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const floa
     }
     __syncthreads();
     const bool found_inf = scale != nullptr && !(fabsf(total) <= 3.4028234664e38f);  // inf or nan; without a scaler torch steps anyway
+    if (blockIdx.x == 0) finish(F, total, found_inf, scale);
     if (!found_inf) {
         const float inv_scale = sh[0], clip = sh[1], step_size = G.step_size, inv_bc2_sqrt = G.inv_bc2_sqrt;
         const float lr_wd = G.lr_wd, w1 = G.w1, b2 = G.b2, w2 = G.w2, eps = G.eps;
@@ -247,41 +284,6 @@ k_opt_adamw(const g2048_opt_chunk *__restrict__ chunks, int n_chunks, const floa
     }
 }
 
-// Bookkeeping after the update, one workgroup: the same total (same order) -> found_inf; step counts, scaler state, info.
-// A launch of its own instead of a "last workgroup done" counter: a device-scope release fence per workgroup makes every
-// one of them write back its XCD's L2 (measured: 114 us for the update kernel instead of 20).
-__global__ void __launch_bounds__(OPT_THREADS)
-k_opt_finish(const float *__restrict__ partial, int n_chunks, float growth, float backoff, int growth_interval, float *__restrict__ steps,
-             int n_steps, float *__restrict__ scale, int32_t *__restrict__ growth_tracker, float *__restrict__ info) {
-    __shared__ float lds[OPT_THREADS / 64];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n_chunks; i += OPT_THREADS) s += partial[i];
-    const float total = block_sum(s, lds);
-    const bool found_inf = scale != nullptr && !(fabsf(total) <= 3.4028234664e38f);
-    if (!found_inf)
-        for (int i = threadIdx.x; i < n_steps; i += OPT_THREADS) steps[i] += 1.f;  // one count per parameter, as torch keeps them
-    if (threadIdx.x == 0) {
-        if (info) {
-            info[0] = sqrtf(total);  // gradient norm (unscaled) before clipping: what clip_grad_norm_ returns
-            info[1] = found_inf ? 1.f : 0.f;
-        }
-        if (scale) {
-            if (found_inf) {
-                *scale *= backoff;
-                *growth_tracker = 0;
-            } else {
-                const int32_t ok = *growth_tracker + 1;
-                if (ok == growth_interval) {
-                    *scale *= growth;
-                    *growth_tracker = 0;
-                } else {
-                    *growth_tracker = ok;
-                }
-            }
-        }
-    }
-}
-
 }  // namespace
 
 extern "C" int g2048_opt_step(const g2048_opt_chunk *chunks, int n_chunks, const float *grads, float *exp_avg, float *exp_avg_sq,
@@ -299,10 +301,11 @@ extern "C" int g2048_opt_step(const g2048_opt_chunk *chunks, int n_chunks, const
     Derived *derived = reinterpret_cast<Derived *>(workspace + ((n_chunks + 3) & ~3));
     hipLaunchKernelGGL(k_opt_sqnorm, dim3((unsigned)n_chunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, chunks, grads, partial, A,
                        n_groups, steps, derived, scale);
+    FinishArgs F;
+    F.growth = growth, F.backoff = backoff, F.growth_interval = growth_interval, F.n_steps = n_steps;
+    F.steps = steps, F.growth_tracker = growth_tracker, F.info = info;
     hipLaunchKernelGGL(k_opt_adamw, dim3((unsigned)n_chunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, chunks, n_chunks, grads,
-                       exp_avg, exp_avg_sq, partial, derived, max_grad_norm, scale);
-    hipLaunchKernelGGL(k_opt_finish, dim3(1), dim3(OPT_THREADS), 0, (hipStream_t)stream, partial, n_chunks, growth, backoff,
-                       growth_interval, steps, n_steps, scale, growth_tracker, info);
+                       exp_avg, exp_avg_sq, partial, derived, max_grad_norm, scale, F);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }

@@ -35,7 +35,7 @@ k_ppo_loss(const void *__restrict__ logits, int logits_bf16, const void *__restr
            const uint8_t *__restrict__ actions, const uint8_t *__restrict__ mask_bits, const float *__restrict__ old_logp,
            const float *__restrict__ adv, const float *__restrict__ ret, int64_t M, float clip_eps, float c_value,
            float c_entropy, float *__restrict__ new_logp, float *__restrict__ sums, void *__restrict__ dlogits,
-           void *__restrict__ dvalues, const float *__restrict__ grad_scale) {
+           void *__restrict__ dvalues, const float *__restrict__ grad_scale, double *__restrict__ running) {
     __shared__ float red[NSUM][THREADS / 64];
     float acc[NSUM] = {0.f, 0.f, 0.f, 0.f, 0.f};  // policy, value, entropy loss, total, old - new log-prob
     const float inv_m = 1.0f / (float)M, lo = 1.0f - clip_eps, hi = 1.0f + clip_eps;
@@ -90,6 +90,7 @@ k_ppo_loss(const void *__restrict__ logits, int logits_bf16, const void *__restr
         float s = 0.f;
         for (int ww = 0; ww < THREADS / 64; ++ww) s += red[threadIdx.x][ww];
         sums[threadIdx.x] = s * inv_m;
+        if (running) running[threadIdx.x] += (double)(s * inv_m);
     }
 }
 
@@ -98,12 +99,12 @@ k_ppo_loss(const void *__restrict__ logits, int logits_bf16, const void *__restr
 extern "C" int g2048_ppo_loss(const void *logits, int logits_bf16, const void *values, int values_bf16, const uint8_t *actions,
                               const uint8_t *mask_bits, const float *old_logp, const float *adv, const float *ret, int64_t M,
                               float clip_eps, float c_value, float c_entropy, float *new_logp, float *sums, void *dlogits,
-                              void *dvalues, const float *grad_scale, void *stream) {
+                              void *dvalues, const float *grad_scale, double *running, void *stream) {
     if (!logits || !values || !actions || !old_logp || !adv || !ret || !new_logp || !sums || !dlogits || !dvalues || M <= 0 ||
         M > G2048_PPO_LOSS_MAX_BATCH)
         return G2048_EINVAL;
     hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(THREADS), 0, (hipStream_t)stream, logits, logits_bf16, values, values_bf16, actions,
-                       mask_bits, old_logp, adv, ret, M, clip_eps, c_value, c_entropy, new_logp, sums, dlogits, dvalues, grad_scale);
+                       mask_bits, old_logp, adv, ret, M, clip_eps, c_value, c_entropy, new_logp, sums, dlogits, dvalues, grad_scale, running);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(1000 + (int)e);
 }

@@ -53,7 +53,7 @@ SIGNATURES = {
                        C.c_float, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_add_ln_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_ppo_loss": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp,
-                       _vp, _vp, _vp],
+                       _vp, _vp, _vp, _vp],
     "g2048_linear_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "g2048_ffn_mask_bytes": [_i64, _i32],
     "g2048_linear_relu_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, C.c_uint64, _vp, _vp, _vp],
@@ -115,7 +115,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
             fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_workspace_bytes", "_partial_rows", "_mask_bytes")) else C.c_int
-        if lib.g2048_abi_version() != 3:
+        if lib.g2048_abi_version() != 4:
             raise NativeError("libg2048.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -583,9 +583,10 @@ def reduce_jobs(jobs):
 
 
 def ppo_loss(logits, values, actions, mask_bits, old_logp, adv, ret, clip_eps: float, c_value: float, c_entropy: float,
-             grad_scale=None):
+             grad_scale=None, running=None):
     """-> (new_logp f32 [M], sums f32 [5], dlogits like logits, dvalues like values); see g2048_ppo_loss.  ``grad_scale``:
-    optional device f32 scalar the two gradients are multiplied by."""
+    optional device f32 scalar the two gradients are multiplied by; ``running``: optional device f64 [5] the kernel adds the
+    five means to."""
     M = actions.numel()
     for name, t in (("logits", logits), ("values", values)):
         if not t.is_cuda or t.dtype not in (torch.bfloat16, f32) or not t.is_contiguous():
@@ -600,7 +601,8 @@ def ppo_loss(logits, values, actions, mask_bits, old_logp, adv, ret, clip_eps: f
         _dev(actions, u8, M, "actions"), _dev(mask_bits, u8, M, "mask_bits", optional=True), _dev(old_logp, f32, M, "old_logp"),
         _dev(adv, f32, M, "adv"), _dev(ret, f32, M, "ret"), M, float(clip_eps), float(c_value), float(c_entropy),
         new_logp.data_ptr(), sums.data_ptr(), dlogits.data_ptr(), dvalues.data_ptr(),
-        _dev(grad_scale, f32, 1, "grad_scale", optional=True), _stream()), "g2048_ppo_loss")
+        _dev(grad_scale, f32, 1, "grad_scale", optional=True), _dev(running, torch.float64, 5, "running", optional=True),
+        _stream()), "g2048_ppo_loss")
     return new_logp, sums, dlogits, dvalues
 
 

@@ -107,12 +107,12 @@ class _MLPUpdate(torch.autograd.Function):
             for wk, bk, dy, x in products:
                 sink.add_dweight(P[wk], P[bk], dy, x, slices, parts_dtype=dtype)
             # trunk_in: dW^T [496][512] = onehot^T dt1 as one more product of the grouped launch (N = 512 padded classes, K = 512), stored
-            # transposed by the reduction; its bias gradient = column sums of dt1
+            # transposed by the reduction; its bias gradient = the column sums of dt1 = row 496 of the same product (the one-hot matrix
+            # carries a column of ones there)
             parts = torch.empty((slices, 512, 512), dtype=dtype, device=dev)
             sink.dw_jobs.append((onehot, dt1, parts, None))
             sink.add(P["win"], parts, 512 * 512, 496 * 512, slices, transpose_rows=496)
-            cs = nv.colsum_partial(dt1)
-            sink.add(P["bin"], cs, 512, 512, cs.shape[0])
+            sink.add(P["bin"], parts.view(slices, 512 * 512)[:, 496 * 512:], 512 * 512, 512, slices)
             rows = ws3.shape[0]
             flat3 = ws3.view(rows, 5 * 512)
             sink.add(P["a3w"], flat3, 5 * 512, 4 * 512, rows)
@@ -123,7 +123,7 @@ class _MLPUpdate(torch.autograd.Function):
         for wk, bk, dy, x in products:
             g[wk] = (dy.float().t() @ x.float())
             g[bk] = dy.float().sum(0)
-        g["win"] = (dt1.float().t() @ onehot.float())[:, :496].contiguous()
+        g["win"] = (dt1.float().t() @ onehot.float())[:, :496].contiguous()  # (column 496 of the one-hot matrix: ones, the bias gradient)
         g["bin"] = dt1.float().sum(0)
         s3 = ws3.sum(0)
         g["a3w"], g["c3w"] = s3[:4].contiguous(), s3[4:5].contiguous()

@@ -93,14 +93,16 @@ class _FusedPPOLoss(torch.autograd.Function):
     Only ``sums[3]`` is differentiable: backward scales the gradients the kernel already produced.  With ``grad_scale`` (the
     GradScaler's device scalar) the kernel itself multiplies them by it and backward passes them on untouched: the caller
     then seeds backward with d(total) = 1 (``sums.backward(selector)``) and gets the gradients of ``grad_scale * total``,
-    i.e. ``scaler.scale(loss).backward()``, without the two scaling launches per minibatch."""
+    i.e. ``scaler.scale(loss).backward()``, without the two scaling launches per minibatch.  ``running`` (device f64 [5]): the
+    kernel also adds the five means to it (the update's logged sums: one launch less per minibatch)."""
 
     @staticmethod
-    def forward(ctx, logits, values, actions_u8, mask_bits, old_lp, adv, ret, clip_eps, c_value, c_entropy, grad_scale=None):
+    def forward(ctx, logits, values, actions_u8, mask_bits, old_lp, adv, ret, clip_eps, c_value, c_entropy, grad_scale=None,
+                running=None):
         from ..g2048 import native as nv
 
         new_lp, sums, dlogits, dvalues = nv.ppo_loss(logits.contiguous(), values.contiguous(), actions_u8, mask_bits, old_lp,
-                                                     adv, ret, clip_eps, c_value, c_entropy, grad_scale)
+                                                     adv, ret, clip_eps, c_value, c_entropy, grad_scale, running)
         ctx.save_for_backward(dlogits, dvalues)
         ctx.prescaled = grad_scale is not None
         ctx.mark_non_differentiable(new_lp)
@@ -111,9 +113,9 @@ class _FusedPPOLoss(torch.autograd.Function):
     def backward(ctx, g_sums, _g_new_lp):
         dlogits, dvalues = ctx.saved_tensors
         if ctx.prescaled:
-            return dlogits, dvalues, None, None, None, None, None, None, None, None, None
+            return (dlogits, dvalues) + (None,) * 10
         g = g_sums[3].to(dlogits.dtype)
-        return dlogits * g, dvalues * g.to(dvalues.dtype), None, None, None, None, None, None, None, None, None
+        return (dlogits * g, dvalues * g.to(dvalues.dtype)) + (None,) * 10
 
 
 class _GraphedFwdBwd:
@@ -134,9 +136,14 @@ class _GraphedFwdBwd:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(3):  # warm-up off the capture stream (allocator, autocast caches, lazy inits)
-                self._zero()
-                self._fwd_bwd()
+            trainer._running_sums()  # (allocated outside the capture)
+            trainer._acc_in_kernel = False  # (the warm-up passes must not count in the update's logged sums)
+            try:
+                for _ in range(3):  # warm-up off the capture stream (allocator, autocast caches, lazy inits)
+                    self._zero()
+                    self._fwd_bwd()
+            finally:
+                trainer._acc_in_kernel = True
         torch.cuda.current_stream().wait_stream(side)
         trainer.optimizer.zero_grad(set_to_none=True)  # backward inside the capture creates the (static) gradients
         self.graph = torch.cuda.CUDAGraph()
@@ -214,6 +221,7 @@ class PPOTrainer:
                  rollout_horizon: Optional[int] = None, allreduce_dtype: Optional[str] = None,
                  allreduce_in_graph: Optional[bool] = None):
         self.agent = agent.to(device)
+        self._acc_in_kernel, self._acc5 = True, None  # see _running_sums
         self.batch_runner = batch_runner
         self.rollout_buffer = rollout_buffer
         self.gamma, self.lambda_gae, self.clip_epsilon = gamma, lambda_gae, clip_epsilon
@@ -302,7 +310,7 @@ class PPOTrainer:
         # armed only around a forward+backward whose gradients ARE all-reduced afterwards (update_policy's eager minibatch, a capture
         # that includes the collectives): a stray backward (graph warm-up, a test calling _loss_backward) must not start one
         self._early_armed = False
-        # clip + AdamW + GradScaler bookkeeping as three launches over flat buffers (g2048_opt_step) for the reference's
+        # clip + AdamW + GradScaler bookkeeping as two launches over flat buffers (g2048_opt_step) for the reference's
         # default optimiser on the device; anything else (LAMB, Adam, CPU) takes the PyTorch calls of the reference
         self._flat_step = None
         if os.environ.get("G2048_FLAT_OPT", "1").strip().lower() not in ("0", "false", "no", "off") \
@@ -614,7 +622,8 @@ class PPOTrainer:
                     scale = self.scaler._scale
                 sums, new_lp = _FusedPPOLoss.apply(logits, values.reshape(-1), actions,
                                                    masks if self.use_action_mask else None, old_lp, adv, ret,
-                                                   self.clip_epsilon, self.value_loss_coef, self.entropy_coef, scale)
+                                                   self.clip_epsilon, self.value_loss_coef, self.entropy_coef, scale,
+                                                   self._running_sums() if self._acc_in_kernel else None)
             else:
                 loss, pl, vl, el, new_lp = self._compute_ppo_loss(obs, actions, masks, old_lp, adv, ret)
         if zero:
@@ -632,7 +641,7 @@ class PPOTrainer:
                 for p, v in zip(self._params, self._flat_views):
                     if id(p) in sink.written:
                         p.grad = v
-            d = sums.detach()  # f32 [5]; the caller accumulates into f64 (one launch per use, no cast kernel)
+            d = sums.detach()  # f32 [5] (the kernel has added them to ``_running_sums()`` already)
             return d[:4], d[4:5]
         if self.use_amp:
             self.scaler.scale(loss).backward()
@@ -651,6 +660,14 @@ class PPOTrainer:
         except BaseException:
             self._early_armed, self._early_work = False, None
             raise
+
+    def _running_sums(self) -> torch.Tensor:
+        """f64 [5] on the device: policy, value, entropy, total loss and KL estimate summed over the minibatches of the current
+        ``update_policy`` call.  ONE buffer for the trainer's lifetime (replayed graphs hold its address); the fused loss kernel adds
+        to it, everything else through ``acc5 +=``."""
+        if getattr(self, "_acc5", None) is None or self._acc5.device != self.device:
+            self._acc5 = torch.zeros(5, dtype=torch.float64, device=self.device)
+        return self._acc5
 
     def _loss_selector(self) -> torch.Tensor:
         """d(total)/d(sums): picks the total loss out of the fused loss kernel's five means."""
@@ -706,7 +723,7 @@ class PPOTrainer:
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self._group)
             n_per_epoch = int(t.item())
         self.agent.train()
-        acc5 = torch.zeros(5, dtype=torch.float64, device=self.device)  # sums over all minibatches: policy, value, entropy, total, kl
+        acc5 = self._running_sums().zero_()  # sums over all minibatches: policy, value, entropy, total, kl
         kl_before = 0.0
         n_updates = 0
         mean_kl = 0.0
@@ -762,7 +779,7 @@ class PPOTrainer:
                     torch.autograd.graph.increment_version(list(self.agent.parameters()))
                 self.lr_scheduler.step()
                 if kl._base is not None and kl._base is stats._base and kl._base.numel() == 5:
-                    acc5 += kl._base  # the fused loss returns views of one [5] tensor: one accumulate launch, not two
+                    pass  # the fused loss (views of its one [5] tensor): g2048_ppo_loss has added them to acc5 itself
                 else:
                     acc5[:4] += stats
                     acc5[4:] += kl

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define G2048_ABI_VERSION 3
+#define G2048_ABI_VERSION 4
 #define G2048_EINVAL (-1)
 #define G2048_RNG_LEGACY 0
 #define G2048_RNG_PARTITIONABLE 1
@@ -316,12 +316,14 @@ int g2048_colsum(const void *x, int is_bf16, int64_t row_stride, int64_t T, int 
  * mean(old_logp - new_logp); dlogits [M][4] and dvalues [M] = d(mean total loss)/d(input) in the input's dtype.
  * total = policy + c_value * value + c_entropy * entropy_loss.  One workgroup, fixed summation order.
  * grad_scale (optional device f32 scalar, e.g. GradScaler's scale): dlogits and dvalues come out multiplied by it, i.e. as
- * the gradients of grad_scale * total (scaler.scale(loss).backward() of the reference, src/ppo/ppo_trainer.py:411-413). */
+ * the gradients of grad_scale * total (scaler.scale(loss).backward() of the reference, src/ppo/ppo_trainer.py:411-413).
+ * running (optional device f64 [5]): running[k] += (double)sums[k] - the per-update accumulation of the logged means
+ * (src/ppo/ppo_trainer.py:424-437 of the reference sums Python floats) without a launch of its own per minibatch. */
 #define G2048_PPO_LOSS_MAX_BATCH 1048576
 int g2048_ppo_loss(const void *logits, int logits_bf16, const void *values, int values_bf16, const uint8_t *actions,
                    const uint8_t *mask_bits, const float *old_logp, const float *adv, const float *ret, int64_t M,
                    float clip_eps, float c_value, float c_entropy, float *new_logp, float *sums, void *dlogits,
-                   void *dvalues, const float *grad_scale, void *stream);
+                   void *dvalues, const float *grad_scale, double *running, void *stream);
 
 /* ---- policy network (update): feed-forward activation ---------------------------------------------------- */
 
@@ -437,7 +439,7 @@ int g2048_reduce_jobs(const g2048_reduce_job *jobs, int n_jobs, void *stream);
 
 /* ---- optimiser step (update) ---------------------------------------------------------------------------- */
 
-/* One optimiser step for every parameter of the agent in three launches: GradScaler unscale + inf check, gradient-norm
+/* One optimiser step for every parameter of the agent in two launches: GradScaler unscale + inf check, gradient-norm
  * clipping, AdamW, GradScaler update (reference: src/ppo/ppo_trainer.py:413-434 = scaler.unscale_(opt);
  * clip_grad_norm_(params, max_grad_norm); scaler.step(opt); scaler.update(), with opt = torch.optim.AdamW built by
  * src/optim/configure_optimizers.py:16-127).

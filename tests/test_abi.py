@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/g2048.h but not exported"
     assert sorted(nv.SIGNATURES) == names  # the ctypes binding covers exactly the header
-    assert nv.load().g2048_abi_version() == 3
+    assert nv.load().g2048_abi_version() == 4
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -85,7 +85,7 @@ def test_invalid_arguments_return_einval_without_touching_a_device():
     assert lib.g2048_embed_fwd(a, a, 30, a, a, a, 4, 0.0, 0, None, None) == -1  # an nn.Linear weight has >= 31 columns
     assert lib.g2048_embed_bwd(a, a, a, None, 4, 0.0, 0, None, None) == -1
     assert lib.g2048_embed_bwd_workspace_floats(4) == 256 * 32 * 256
-    assert lib.g2048_ppo_loss(a, 0, a, 0, a, None, a, a, a, 0, 0.2, 0.5, 0.01, a, a, a, a, None, None) == -1   # M = 0
+    assert lib.g2048_ppo_loss(a, 0, a, 0, a, None, a, a, a, 0, 0.2, 0.5, 0.01, a, a, a, a, None, None, None) == -1   # M = 0
     assert lib.g2048_gather_minibatch(a, 4, 0, a, a, a, a, a, a, a, a, a, a, a, a, None) == -1           # empty buffer
 
 

@@ -56,6 +56,7 @@ def test_mlp_embed_and_output_kernels(dev):
     nv.mlp_embed_fwd(boards, w.t().contiguous(), bias, y, oh)
     cols = boards.long() + torch.arange(16, device=dev) * 31
     onehot = torch.zeros(M, 512, device=dev).scatter_(1, cols, 1.0)
+    onehot[:, 496] = 1.0  # the column of ones whose row of onehot^T dY is trunk_in's bias gradient
     assert torch.equal(oh.float(), onehot)
     want = torch.relu(onehot[:, :496] @ w.float().t() + bias)
     assert rel(y, want) < 3e-3

@@ -1,4 +1,4 @@
-"""g2048_opt_step (clip + AdamW + GradScaler in three launches) against the PyTorch calls of the reference's update loop
+"""g2048_opt_step (clip + AdamW + GradScaler in two launches) against the PyTorch calls of the reference's update loop
 (src/ppo/ppo_trainer.py:413-434): scaler.unscale_, clip_grad_norm_, scaler.step(AdamW), scaler.update."""
 import copy
 

@@ -608,6 +608,12 @@ def test_fused_ppo_loss_matches_torch(dev, dtype, use_mask):
         assert torch.allclose(dv.float(), v32.grad, **gtol)
         assert torch.equal(sums, nv.ppo_loss(logits, values, actions.to(torch.uint8), bits if use_mask else None, old_lp, adv,
                                              ret, 0.2, 0.5, 0.01)[1])  # fixed summation order
+        # the running f64 sums the trainer logs from: exactly what `acc += sums.double()` gives, call after call
+        run = torch.full((5,), 2.0, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            nv.ppo_loss(logits, values, actions.to(torch.uint8), bits if use_mask else None, old_lp, adv, ret, 0.2, 0.5, 0.01,
+                        running=run)
+        assert torch.equal(run, 2.0 + sums.double() + sums.double() + sums.double())
 
 
 def test_relu_dropout_kernels(dev):
