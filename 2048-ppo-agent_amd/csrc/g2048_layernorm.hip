@@ -460,15 +460,27 @@ namespace {
 
 constexpr int EMB_D = 256, EMB_CLASSES = 32, EMB_SEQ = 17, EMB_BLOCKS = 256;
 
+// LN: also h = bf16(LayerNorm(x0 row)) and the row's mean / rstd - the first LayerNorm of the encoder (layers[0].norm1) on the row the
+// wave still holds, in k_add_ln_fwd's arithmetic (that launch read the 36 MB back for it: 13.7 us per minibatch)
+struct EmbedLN {
+    const float *gamma, *beta;
+    uint16_t *h;
+    float *mean, *rstd;
+    float eps;
+};
+
+template <bool LN>
 __global__ void __launch_bounds__(256)
 k_embed_fwd(const uint8_t *__restrict__ boards, const float *__restrict__ wt, int w_ld, const float *__restrict__ pe,
             const float *__restrict__ cls, float *__restrict__ x0, int64_t n_rows, float inv_keep, uint32_t thr, uint32_t s0,
-            uint32_t s1, const uint64_t *seed_state) {
+            uint32_t s1, const uint64_t *seed_state, EmbedLN L) {
     // the nn.Linear weight itself ([256][w_ld], w_ld >= 31) is turned into the class-major table [31][256] in LDS once per workgroup:
     // read per row it was four strided 4-byte loads per lane (19 us per launch for 36 MB of output)
     __shared__ __attribute__((aligned(16))) float table[31 * EMB_D];
     mix_seed_state(seed_state, s0, s1);
     const int lane = threadIdx.x & 63;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), bt = g;
+    if (LN) g = reinterpret_cast<const float4 *>(L.gamma)[lane], bt = reinterpret_cast<const float4 *>(L.beta)[lane];
     if (w_ld != 0) {
         const float *w = wt + (size_t)threadIdx.x * w_ld;  // thread d copies row d of the weight into column d of the table
         for (int e = 0; e < 31; ++e) table[e * EMB_D + threadIdx.x] = w[e];
@@ -495,6 +507,18 @@ k_embed_fwd(const uint8_t *__restrict__ boards, const float *__restrict__ wt, in
             }
         }
         reinterpret_cast<float4 *>(x0 + row * EMB_D)[lane] = v;
+        if (LN) {
+            const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / EMB_D);
+            const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+            const float rstd = rsqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / EMB_D) + L.eps);
+            const uint32_t lo = f2bf(dx * rstd * g.x + bt.x) | (f2bf(dy * rstd * g.y + bt.y) << 16);
+            const uint32_t hi = f2bf(dz * rstd * g.z + bt.z) | (f2bf(dw * rstd * g.w + bt.w) << 16);
+            reinterpret_cast<uint2 *>(L.h + row * EMB_D)[lane] = make_uint2(lo, hi);
+            if (lane == 0) {
+                L.mean[row] = mean;
+                L.rstd[row] = rstd;
+            }
+        }
     }
 }
 
@@ -562,8 +586,26 @@ extern "C" int g2048_embed_fwd(const uint8_t *boards, const float *wt, int w_ld,
     const int64_t n_rows = M * EMB_SEQ;
     int64_t blocks = (n_rows + 3) / 4;
     if (blocks > 1024) blocks = 1024;  // four workgroups per CU: the table is staged 1 024 times (32 MB of L2 reads)
-    hipLaunchKernelGGL(k_embed_fwd, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, boards, wt, w_ld, pe, cls, x0, n_rows,
-                       1.0f / (1.0f - p_drop), (uint32_t)(p_drop * 16777216.0f), (uint32_t)seed, (uint32_t)(seed >> 32), seed_state);
+    hipLaunchKernelGGL(k_embed_fwd<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, boards, wt, w_ld, pe, cls, x0, n_rows,
+                       1.0f / (1.0f - p_drop), (uint32_t)(p_drop * 16777216.0f), (uint32_t)seed, (uint32_t)(seed >> 32), seed_state,
+                       EmbedLN{});
+    return done();
+}
+
+extern "C" int g2048_embed_ln_fwd(const uint8_t *boards, const float *wt, int w_ld, const float *pe, const float *cls, float *x0, int64_t M,
+                                  float p_drop, uint64_t seed, const uint64_t *seed_state, const float *gamma, const float *beta, float eps,
+                                  void *h, float *mean, float *rstd, void *stream) {
+    if (!boards || !wt || !pe || !cls || !x0 || M <= 0 || !(p_drop >= 0.f && p_drop < 1.f) || (w_ld != 0 && w_ld < 31) || !gamma || !beta ||
+        !h || !mean || !rstd || (((uintptr_t)pe | (uintptr_t)cls | (uintptr_t)x0 | (uintptr_t)gamma | (uintptr_t)beta) & 15) ||
+        ((uintptr_t)h & 7) || ((uintptr_t)wt & (w_ld ? 3 : 15)))
+        return G2048_EINVAL;
+    const int64_t n_rows = M * EMB_SEQ;
+    int64_t blocks = (n_rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    EmbedLN L;
+    L.gamma = gamma, L.beta = beta, L.h = (uint16_t *)h, L.mean = mean, L.rstd = rstd, L.eps = eps;
+    hipLaunchKernelGGL(k_embed_fwd<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, boards, wt, w_ld, pe, cls, x0, n_rows,
+                       1.0f / (1.0f - p_drop), (uint32_t)(p_drop * 16777216.0f), (uint32_t)seed, (uint32_t)(seed >> 32), seed_state, L);
     return done();
 }
 

@@ -60,6 +60,7 @@ SIGNATURES = {
     "g2048_linear_mask_bwd_workspace_floats": [_i64, _i32],
     "g2048_linear_mask_bwd_bf16": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, C.c_float, _vp],
     "g2048_embed_fwd": [_vp, _vp, C.c_int, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
+    "g2048_embed_ln_fwd": [_vp, _vp, C.c_int, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp],
     "g2048_embed_bwd_workspace_floats": [_i64],
     "g2048_embed_bwd": [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_uint64, _vp, _vp],
     "g2048_gather_minibatch": [_vp, _i64, _i64] + [_vp] * 13,
@@ -668,12 +669,22 @@ def linear_mask_bwd(dy2: torch.Tensor, weight_t: torch.Tensor, mask: torch.Tenso
     return dz, ws[:rows * N].view(rows, N)
 
 
-def embed_fwd(boards, wt, pe, cls, x0, p_drop: float = 0.0, seed: int = 0, seed_state: int = 0):
-    """wt: the class-major table f32 [31, 256], or the nn.Linear weight f32 [256, 31] itself (read in place)."""
+def embed_fwd(boards, wt, pe, cls, x0, p_drop: float = 0.0, seed: int = 0, seed_state: int = 0, ln=None):
+    """wt: the class-major table f32 [31, 256], or the nn.Linear weight f32 [256, 31] itself (read in place).  ``ln`` = (gamma f32
+    [256], beta f32 [256], eps, h bf16 [M, 17, 256], mean f32 [M * 17], rstd f32 [M * 17]): also the LayerNorm of every row
+    (``g2048_embed_ln_fwd``)."""
     M = boards.numel() // 16
     w_ld = 0 if tuple(wt.shape) == (31, 256) else int(wt.shape[1])
     if w_ld and (wt.dim() != 2 or wt.shape[0] != 256 or w_ld < 31):
         raise NativeError(f"embed_fwd: weight must be [31, 256] or [256, >= 31], got {tuple(wt.shape)}")
+    if ln is not None:
+        gamma, beta, eps, h, mean, rstd = ln
+        _check(load().g2048_embed_ln_fwd(_dev(boards, u8, 16 * M, "boards"), _dev(wt, f32, 31 * 256, "wt"), w_ld,
+                                         _dev(pe, f32, 16 * 256, "pe"), _dev(cls, f32, 256, "cls"), _dev(x0, f32, M * 17 * 256, "x0"), M,
+                                         float(p_drop), int(seed), seed_state or None, _dev(gamma, f32, 256, "gamma"),
+                                         _dev(beta, f32, 256, "beta"), float(eps), _dev(h, torch.bfloat16, M * 17 * 256, "h"),
+                                         _dev(mean, f32, M * 17, "mean"), _dev(rstd, f32, M * 17, "rstd"), _stream()), "g2048_embed_ln_fwd")
+        return
     _check(load().g2048_embed_fwd(_dev(boards, u8, 16 * M, "boards"), _dev(wt, f32, 31 * 256, "wt"), w_ld,
                                   _dev(pe, f32, 16 * 256, "pe"),
                                   _dev(cls, f32, 256, "cls"), _dev(x0, f32, M * 17 * 256, "x0"), M, float(p_drop), int(seed),

@@ -510,15 +510,25 @@ class _InProjCls(torch.autograd.Function):
     """in_proj of the LAST layer when only the CLS row is wanted: q = h[:, :1] Wq^T + bq, kv = h Wkv^T + bkv, with
     the gradients of the whole in_proj weight and bias assembled in one buffer (slicing the parameter instead costs a
     zero-fill, a copy and an accumulate per slice in the backward).  h, wb, bb bf16; weight/bias the f32 masters.
-    The CLS rows are first gathered into a contiguous [B, D] matrix (one 1 MB copy at minibatch 2048), so that no GEMM
-    of the update takes the [B, 1, D] view with row stride 17 * D as an operand (NOTES.md 3, "the 02:59 fault")."""
+    The query projection reads the CLS rows in place (row stride S * D) through ``g2048_gemm_jobs``; where that kernel does not apply
+    they are first gathered into a contiguous [B, D] matrix, so that no LIBRARY GEMM of the update takes the [B, 1, D] view with row
+    stride 17 * D as an operand (NOTES.md 3, "the 02:59 fault")."""
 
     @staticmethod
     def forward(ctx, h, weight, bias, wb, bb, h_link=None, wt_packed=None):
+        from ..g2048 import native as nv
+
         ctx.h_link, ctx.wt_packed = h_link, wt_packed  # (HLink: the producer of h may run the K/V input-gradient GEMM itself)
         B, S, D = h.shape
-        h_cls = h[:, 0].contiguous()
-        q = F.linear(h_cls, wb[:D], bb[:D]).view(B, 1, D)
+        h_cls = None
+        if (h.is_cuda and h.dtype == torch.bfloat16 and h.is_contiguous() and wb.dtype == torch.bfloat16 and D % 64 == 0
+                and bias.dtype == torch.float32 and h.data_ptr() % 16 == 0):
+            q = torch.empty((B, D), dtype=torch.bfloat16, device=h.device)
+            nv.gemm_jobs([dict(segs=[(h[:, 0], wb[:D])], bias=bias.detach()[:D], y=q)], B)
+            q = q.view(B, 1, D)
+        else:
+            h_cls = h[:, 0].contiguous()
+            q = F.linear(h_cls, wb[:D], bb[:D]).view(B, 1, D)
         kv = None
         if bias.dtype == torch.float32:
             kv = _hip_linear(h.reshape(B * S, D), wb[D:], bias.detach()[D:])
@@ -526,13 +536,15 @@ class _InProjCls(torch.autograd.Function):
                 kv = kv.view(B, S, 2 * D)
         if kv is None:
             kv = F.linear(h, wb[D:], bb[D:])
-        ctx.save_for_backward(h, h_cls, wb)
+        ctx.save_for_backward(h, wb)
         ctx.params = (weight, bias)
         return q, kv
 
     @staticmethod
     def backward(ctx, dq, dkv):
-        h, h_cls, wb = ctx.saved_tensors
+        from ..g2048 import native as nv
+
+        h, wb = ctx.saved_tensors
         B, S, D = h.shape
         dq2, dkv2 = dq.reshape(B, D).contiguous(), dkv.reshape(B * S, 2 * D).contiguous()
         dh = None
@@ -553,9 +565,13 @@ class _InProjCls(torch.autograd.Function):
             torch.addmm(dh0, dq2, wb[:D], out=dh0)
         weight, bias = ctx.params
         sink = _sink_for(weight, bias)
+        # the CLS rows in place for our own weight-gradient GEMM (the grouped launch, which also sums dq's columns = the query bias
+        # gradient); a contiguous copy for everything else
+        h_cls = h[:, 0]
+        if not (sink is not None and B >= 2048 and nv.dweight_ok(dq2, h_cls, _dweight_parts_config()[0])):
+            h_cls = h_cls.contiguous()
         if sink is not None:  # the four pieces land in their slices of the in_proj gradients
-            _sink_weight(sink, weight, dq2, h_cls, 0)
-            _sink_bias(sink, bias, dq2, 0)
+            _sink_weight_bias(sink, weight, bias, dq2, h_cls, 0, 0)
             _sink_weight_bias(sink, weight, bias, dkv2, h.view(B * S, D), D * D, D)
             return dh, None, None, None, None, None, None
 
@@ -679,25 +695,31 @@ class _AddLayerNorm(torch.autograd.Function):
     x f32 [..., 256] (a [B, 1, 256] slice of the residual stream is read in place), a bf16; returns (x_new, h)."""
 
     @staticmethod
-    def forward(ctx, x, a, gamma, beta, eps, p_drop, h_link=None):
+    def forward(ctx, x, a, gamma, beta, eps, p_drop, h_link=None, pre=None):
         from ..g2048 import native as nv
 
         ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None, not as a zero-filled tensor
         ctx.h_link = h_link
         if h_link is not None:
             h_link.armed = _rowgemm_on()
+        x_in = x
         x, row_stride = _residual_rows(x)
         T = x.numel() // 256
         gamma, beta = gamma.contiguous(), beta.contiguous()
-        h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-        stats = torch.empty((2, T), dtype=torch.float32, device=x.device)
         x_new = None
         seed = (0, 0)
-        if a is not None:
-            a = a.contiguous()
-            x_new = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-            seed = _seed_pair(x, p_drop)
-        nv.add_ln_fwd(x.data_ptr(), row_stride, a, gamma, beta, x_new, h, stats[0], stats[1], T, eps, p_drop, *seed)
+        if a is None and pre is not None and pre.h is not None and pre.x is not None and pre.x.data_ptr() == x_in.data_ptr() \
+                and x is x_in and pre.h.shape == x.shape:
+            h, stats = pre.h, pre.stats  # the producer of x normalised its rows already (LNPre)
+            pre.x = pre.h = pre.stats = None
+        else:
+            h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+            stats = torch.empty((2, T), dtype=torch.float32, device=x.device)
+            if a is not None:
+                a = a.contiguous()
+                x_new = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                seed = _seed_pair(x, p_drop)
+            nv.add_ln_fwd(x.data_ptr(), row_stride, a, gamma, beta, x_new, h, stats[0], stats[1], T, eps, p_drop, *seed)
         ctx.params = (gamma, beta)
         if a is None:
             # x itself is the first output: the residual stream continues from THIS node, so the gradient of the stream and
@@ -736,8 +758,8 @@ class _AddLayerNorm(torch.autograd.Function):
         if sink is not None:
             sink.add(ctx.params[0], ws, 768, 256, ws.shape[0])
             sink.add(ctx.params[1], ws[:, 256:], 768, 256, ws.shape[0])
-            return dx, da, None, None, None, None, None
-        return dx, da, dparams[0], dparams[1], None, None, None
+            return dx, da, None, None, None, None, None, None
+        return dx, da, dparams[0], dparams[1], None, None, None, None
 
 
 def _residual_rows(x: torch.Tensor):
@@ -997,15 +1019,31 @@ def _fused_norm_ok(x: torch.Tensor, a) -> bool:
             and (a is None or a.dtype == torch.bfloat16))
 
 
-def _add_norm(x: torch.Tensor, a, norm: nn.LayerNorm, p: float, training: bool, h_link=None):
-    """(x + dropout(a), LayerNorm(x + dropout(a))); ``a`` None: (x, LayerNorm(x)).  ``h_link``: see ``HLink``."""
+def _add_norm(x: torch.Tensor, a, norm: nn.LayerNorm, p: float, training: bool, h_link=None, pre=None):
+    """(x + dropout(a), LayerNorm(x + dropout(a))); ``a`` None: (x, LayerNorm(x)).  ``h_link``: see ``HLink``; ``pre``: see ``LNPre``."""
     if _fused_norm_ok(x, a):
         if a is None and _residual_rows(x)[0] is not x:  # a copy would be made: keep the caller's x as the stream
             return x, _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, 0.0)[1]
-        return _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, p if training else 0.0, h_link)
+        return _AddLayerNorm.apply(x, a, norm.weight, norm.bias, norm.eps, p if training else 0.0, h_link, pre)
     if a is not None:
         x = x + F.dropout(a, p, training)
     return x, F.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)
+
+
+class LNPre:
+    """Lets the node that PRODUCES the token matrix (``_EmbedBoards``) also run the first LayerNorm of the encoder on the rows it
+    holds (``g2048_embed_ln_fwd``): it leaves h and the row statistics here, and the ``_AddLayerNorm`` node of that LayerNorm (``a``
+    None) takes them instead of launching ``g2048_add_ln_fwd`` over the same 36 MB.  The backward is untouched (two nodes)."""
+
+    __slots__ = ("norm", "x", "h", "stats")
+
+    def __init__(self, norm: nn.LayerNorm):
+        self.norm, self.x, self.h, self.stats = norm, None, None, None
+
+    def usable(self) -> bool:
+        n = self.norm
+        return (n.weight is not None and n.bias is not None and n.weight.dtype == torch.float32 and n.bias.dtype == torch.float32
+                and tuple(n.weight.shape) == (256,))
 
 
 class _EmbedBoards(torch.autograd.Function):
@@ -1015,7 +1053,7 @@ class _EmbedBoards(torch.autograd.Function):
     emb_weight: the bias-free input Linear's weight [256, 31]; pe f32 [16, 256]; cls [1, 1, 256]."""
 
     @staticmethod
-    def forward(ctx, boards, emb_weight, pe, cls, p_drop):
+    def forward(ctx, boards, emb_weight, pe, cls, p_drop, pre=None):
         from ..g2048 import native as nv
 
         boards = boards.contiguous()
@@ -1025,7 +1063,14 @@ class _EmbedBoards(torch.autograd.Function):
         wt = w if (w.dtype == torch.float32 and w.is_contiguous()) else w.float().t().contiguous()
         x0 = torch.empty((M, 17, 256), dtype=torch.float32, device=boards.device)
         seed = _seed_pair(x0, p_drop)
-        nv.embed_fwd(boards, wt, pe, cls.detach().float().reshape(256).contiguous(), x0, p_drop, *seed)
+        ln = None
+        if pre is not None and pre.usable():
+            n = pre.norm
+            pre.h = torch.empty((M, 17, 256), dtype=torch.bfloat16, device=boards.device)
+            pre.stats = torch.empty((2, M * 17), dtype=torch.float32, device=boards.device)
+            pre.x = x0
+            ln = (n.weight.detach().contiguous(), n.bias.detach().contiguous(), n.eps, pre.h, pre.stats[0], pre.stats[1])
+        nv.embed_fwd(boards, wt, pe, cls.detach().float().reshape(256).contiguous(), x0, p_drop, *seed, ln=ln)
         ctx.save_for_backward(boards)
         ctx.meta = (p_drop, seed, emb_weight.dtype, cls.dtype)
         ctx.params = (emb_weight, cls)
@@ -1043,10 +1088,10 @@ class _EmbedBoards(torch.autograd.Function):
             ws = nv.embed_bwd(boards, g.contiguous(), None, p_drop, *seed)
             sink.add(emb_weight, ws, ws.shape[1], 31 * 256, ws.shape[0], transpose_rows=31)
             sink.add(cls, ws[:, 31 * 256:], ws.shape[1], 256, ws.shape[0])
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         out = torch.empty((32, 256), dtype=torch.float32, device=g.device)
         nv.embed_bwd(boards, g.contiguous(), out, p_drop, *seed)
-        return None, out[:31].t().to(w_dtype), None, out[31].view(1, 1, 256).to(c_dtype), None
+        return None, out[:31].t().to(w_dtype), None, out[31].view(1, 1, 256).to(c_dtype), None, None
 
 
 def _fused_attention_ok(t: torch.Tensor, S: int, head_dim: int) -> bool:

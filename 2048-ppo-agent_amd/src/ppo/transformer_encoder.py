@@ -7,13 +7,14 @@ out explicitly (pre-norm layers over fused QKV) so that the update path can run 
 without a HIP device, gradients or bf16 autocast every step falls back to the PyTorch operator it mirrors.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..env_definitions import BOARD_DIM
-from .hip_ops import (Bf16Shadow, ClsLink, FFNLink, HLink, _AddLayerNorm, _ClsRows, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
+from .hip_ops import (Bf16Shadow, ClsLink, FFNLink, HLink, LNPre, _AddLayerNorm, _ClsRows, _AttnCls, _AttnPacked, _EmbedBoards, _ExpandRows, _InProjCls,  # noqa: F401
                       _LinearAddCast, _LinearAddLayerNorm, _LinearReluDropout, _LinearSplitK, _add_norm, _fused_attention_ok, _fused_norm_ok,
                       _linear, _train_bf16, graph_seed_state)
 
@@ -196,9 +197,11 @@ class TransformerEncoder(nn.Module):
         ``encode``) possibly the heads' outputs instead."""
         pe = self.positional_encoding.flat_table().float().contiguous()
         p = self.positional_encoding.dropout.p if self.training else 0.0
-        return self.encode(_EmbedBoards.apply(boards, emb_weight, pe, self.cls_token, p), reduction, tail_heads)
+        # (the embedding kernel also normalises its rows for layers[0].norm1: LNPre)
+        pre = LNPre(self.encoder.layers[0].norm1) if os.environ.get("G2048_EMBED_LN", "1") != "0" else None
+        return self.encode(_EmbedBoards.apply(boards, emb_weight, pe, self.cls_token, p, pre), reduction, tail_heads, pre=pre)
 
-    def encode(self, x: torch.Tensor, reduction: str = "mean", tail_heads=None):
+    def encode(self, x: torch.Tensor, reduction: str = "mean", tail_heads=None, pre=None):
         """[B, 17, d_model] tokens (CLS first, positions added) through the encoder layers -> [B, d_model].
         ``tail_heads(o, x_cls, params, dense, transposed, eps, p) -> (logits, values)``: offered by an agent whose heads can run
         inside the fused CLS tail; when the update path takes it, the return value is that tuple instead of the features."""
@@ -210,7 +213,7 @@ class TransformerEncoder(nn.Module):
         # h_links[i]: joins the node that produces layer i's normalised input with that layer's in_proj (whose fragment-packed
         # transposed weight sh[i][12] exists for the layers in front of the last one): see hip_ops.HLink
         h_links = [HLink() if sh[i][12] is not None else None for i in range(len(layers))]
-        x, h = _add_norm(x, None, layers[0].norm1, 0.0, self.training, h_link=h_links[0])
+        x, h = _add_norm(x, None, layers[0].norm1, 0.0, self.training, h_link=h_links[0], pre=pre)
         # update path with a CLS-only last layer: its CLS-row gradient goes straight into the backward kernel of the layer
         # before it (ClsLink) instead of through a zero-filled [B, 17, 256] tensor
         cls_link = ClsLink() if (reduction == "cls" and last >= 1 and sh[0][0] is not None) else None

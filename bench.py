@@ -117,7 +117,7 @@ def step_kernel_roofline(dev, boards_per_launch: int, launches: int = 20):
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "step_kernel_pmc_latest.json")))
         traffic = round(pmc["hbm_bytes_per_env_step"] * B)
-        traffic_source = f"profiles/step_kernel_pmc_latest.json ({pmc.get('measured_in', 'round 1')}, kernel unchanged since; not measured in this run)"
+        traffic_source = f"profiles/step_kernel_pmc_latest.json ({pmc.get('measured_in', 'round 1')}, re-measured whenever g2048.hip changes; not measured in this run)"
     except Exception:
         pass
     ginstr = STEP_VALU_PER_WAVE * (B / 64) / (us * 1e-6) / 1e9

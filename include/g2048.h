@@ -412,6 +412,12 @@ int g2048_embed_fwd(const uint8_t *boards, const float *wt, int w_ld, const floa
  * summation order.  dx0 f32 [M][17][256]; workspace: g2048_embed_bwd_workspace_floats(M) floats.  dwt_dcls NULL: first
  * stage only, the workspace then holds f32 [workspace floats / 8192][32 * 256] partial sums for g2048_reduce_jobs (whose
  * transpose_rows = 31 stores the first 31 * 256 columns as the [256][31] gradient of the nn.Linear weight). */
+/* The same, and on the row it still holds h[m][t] = bf16(LayerNorm(x0[m][t]) * gamma + beta) with mean / rstd f32 [M * 17]: the first
+ * LayerNorm of the encoder (layers[0].norm1, src/ppo/transformer_encoder.py:138-148 norm_first) in g2048_add_ln_fwd's arithmetic, without
+ * reading x0 back.  gamma, beta f32 [256]; h bf16 [M][17][256]. */
+int g2048_embed_ln_fwd(const uint8_t *boards, const float *wt, int w_ld, const float *pe, const float *cls, float *x0, int64_t M,
+                       float p_drop, uint64_t seed, const uint64_t *seed_state, const float *gamma, const float *beta, float eps,
+                       void *h, float *mean, float *rstd, void *stream);
 int64_t g2048_embed_bwd_workspace_floats(int64_t M);
 int g2048_embed_bwd(const uint8_t *boards, const float *dx0, float *dwt_dcls, float *workspace, int64_t M, float p_drop,
                     uint64_t seed, const uint64_t *seed_state, void *stream);

@@ -828,6 +828,51 @@ def test_linear_bf16_matches_torch(dev):
         nv.linear_bf16(torch.zeros(8, 100, device=dev, dtype=torch.bfloat16), torch.zeros(128, 100, device=dev, dtype=torch.bfloat16))
 
 
+def test_embed_with_first_layernorm_equals_the_two_launches(dev, monkeypatch):
+    """g2048_embed_ln_fwd = g2048_embed_fwd followed by g2048_add_ln_fwd over the same rows, bit for bit (tokens, normalised bf16 rows,
+    means, rstds; with and without the positional dropout), and the agent's update forward / backward with the embedding kernel
+    normalising for layers[0].norm1 (LNPre) equals the run with the separate launch (G2048_EMBED_LN=0) bit for bit."""
+    from src.g2048 import native as nv
+    from src.ppo import PPOAgent
+
+    torch.manual_seed(23)
+    for M, p in ((1, 0.0), (300, 0.0), (2048, 0.1)):
+        boards = torch.randint(0, 18, (M, 16), device=dev, dtype=torch.uint8)
+        w, pe, cls = torch.randn(256, 31, device=dev), torch.randn(16, 256, device=dev), torch.randn(256, device=dev)
+        gamma, beta = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev) * 0.1
+        x_a, x_b = torch.empty(M, 17, 256, device=dev), torch.empty(M, 17, 256, device=dev)
+        h_a, h_b = (torch.empty(M, 17, 256, device=dev, dtype=torch.bfloat16) for _ in range(2))
+        st_a, st_b = torch.empty(2, M * 17, device=dev), torch.empty(2, M * 17, device=dev)
+        nv.embed_fwd(boards, w, pe, cls, x_a, p, 1234, 0, ln=(gamma, beta, 1e-5, h_a, st_a[0], st_a[1]))
+        nv.embed_fwd(boards, w, pe, cls, x_b, p, 1234, 0)
+        nv.add_ln_fwd(x_b.data_ptr(), 256, None, gamma, beta, None, h_b, st_b[0], st_b[1], M * 17, 1e-5, 0.0, 0, 0)
+        assert torch.equal(x_a, x_b) and torch.equal(h_a, h_b) and torch.equal(st_a, st_b), (M, p)
+    with pytest.raises(nv.NativeError):
+        nv.embed_fwd(boards, w, pe, cls, x_a, 0.0, 0, 0, ln=(gamma.double(), beta, 1e-5, h_a, st_a[0], st_a[1]))
+
+    torch.manual_seed(5)
+    agent = PPOAgent(dropout=0.0, reduction="cls").to(dev).train()  # (no dropout: every launch of the two runs is deterministic)
+    boards = torch.randint(0, 12, (256, 16), device=dev, dtype=torch.uint8)
+
+    def run(flag):
+        monkeypatch.setenv("G2048_EMBED_LN", flag)
+        calls = []
+        real = nv.add_ln_fwd
+        monkeypatch.setattr(nv, "add_ln_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        agent.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lo, va = agent(boards, None)
+        (lo.float().square().sum() + va.float().sum()).backward()
+        monkeypatch.setattr(nv, "add_ln_fwd", real)
+        return lo.detach().clone(), va.detach().clone(), [p.grad.clone() for p in agent.parameters()], len(calls)
+
+    lo1, va1, g1, n1 = run("1")
+    lo0, va0, g0, n0 = run("0")
+    assert n0 == n1 + 1, (n0, n1)  # one g2048_add_ln_fwd launch less
+    assert torch.equal(lo1, lo0) and torch.equal(va1, va0)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g0))
+
+
 def test_embed_boards_matches_torch(dev):
     """g2048_embed_fwd/bwd (gather + segmented sum) vs one-hot Linear + positional add + CLS concat in PyTorch: tokens and
     the gradients of the embedding weight and the CLS token; with dropout only board tokens are dropped, the backward

@@ -99,7 +99,8 @@ def test_default_shape_agent_on_every_device_path(dev):
             lh, vh = agent(boards, None)
     finally:
         nv.attn_fwd, nv.add_ln_fwd, nv.embed_fwd = orig
-    assert calls["attn"] == 8 and calls["ln"] >= 16 and calls["embed"] == 2, calls  # 2 forwards x 4 layers
+    # 2 forwards x 4 layers (the first LayerNorm of each forward runs inside the embedding kernel: g2048_embed_ln_fwd)
+    assert calls["attn"] == 8 and calls["ln"] >= 14 and calls["embed"] == 2, calls
     err_f = (fh.float() - want["features"]).abs().mean().item()
     assert err_f < 1.5 * base_f + 1e-4, (err_f, base_f)
     assert (lh.float() - want["logits"]).abs().max().item() < 2.0 * base_l + 0.02
