@@ -15,11 +15,15 @@
 //     features; wave w owns features 32 w .. 32 w + 31 for every token: up to five 32 x 32 accumulator tiles (80 registers);
 //   * computed transposed like every GEMM of this library, Y^T[n][token] = W[n][k] X^T[k][token] with v_mfma_f32_32x32x16_bf16: the
 //     weight is the A operand, read from its FRAGMENT-PACKED bf16 shadow (include/g2048.h: one contiguous KB per wave-instruction,
-//     L2-resident: 128-512 KB shared by all workgroups) straight into registers, one 128-wide K-chunk (8 fragments) ahead;
+//     L2-resident: 128-512 KB shared by all workgroups) straight into registers through a ring of four fragments (fragment g + 4 is
+//     requested right behind the MFMAs that last read fragment g);
 //   * X streams through LDS in K-chunks of 128: [160 tokens][256 B], 16-byte pieces XOR-swizzled by row so that a B fragment is one
-//     conflict-free ds_read_b128; the chunk after next is in flight in registers (global_load -> ds_write, all of it visible to the
-//     compiler's wait-count pass: no LDS-DMA here, because the weight fragments are register loads in the same in-order queue and an
-//     inline-assembly DMA beside them would make every compiler-generated wait a vmcnt(0)); two chunks = 70 KB per CU in flight;
+//     conflict-free ds_read_b128; chunk c is multiplied from one LDS stage while chunk c + 1 is written to the other and chunks c + 2,
+//     c + 3 are in flight in registers (global_load -> ds_write, all of it visible to the compiler's wait-count pass: no LDS-DMA here,
+//     because the weight fragments are register loads in the same in-order queue and an inline-assembly DMA beside them would make every
+//     compiler-generated wait a vmcnt(0)).  The K-loop is a template over K / 128 and fully unrolled - every prefetch decision is a
+//     compile-time one (a run-time `if` around a load or an MFMA costs a vmcnt(0) in front of every MFMA) - with the chunk's addresses
+//     derived from a run-time counter, so that the unrolled code does not keep 40 precomputed addresses in registers;
 //   * one barrier per chunk (LDS-only: __syncthreads() would drain the prefetch);
 //   * epilogue: the output tile goes to LDS as bf16 rows (the rounding of the unfused Linear's output), then every wave walks rows of
 //     it exactly as g2048_add_ln_fwd / _bwd do (one wavefront per token row, 4 features per lane, statistics by wave reduction, the
