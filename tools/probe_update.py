@@ -1,5 +1,5 @@
 """Where does one PPO minibatch go?  wall ms/minibatch (eager and hipGraph), GPU-busy ms, kernels per minibatch,
-and the kernel table by time and by launch count.  usage: python tools/probe_update.py [rows]"""
+and the kernel table by time and by launch count.  usage: python tools/probe_update.py [rows] [--mlp] [--eager] [--timeline] [--hostprof]"""
 import os
 import sys
 import time
@@ -41,6 +41,18 @@ if "--eager" in sys.argv:
     tr.use_hip_graph = False
     print("eager warm", upd())
     print("eager", upd())
+if "--hostprof" in sys.argv:  # where the HOST side of a minibatch goes (matters when the GPU work per minibatch is ~0.15 ms: the MLP policy)
+    import cProfile
+    import pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
+    _, _, n_h = upd()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats("cumulative")
+    print(f"host profile over {n_h} minibatches (cumulative seconds; divide by {n_h} for per-minibatch):")
+    st.print_stats(28)
 from torch.profiler import ProfilerActivity, profile
 
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
@@ -56,7 +68,7 @@ for k in sorted(ka, key=lambda k: -k.count)[:rows]:
 if "--timeline" in sys.argv:  # one minibatch in launch order: offset, duration, idle gap before the kernel
     ev = sorted((e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and e.time_range is not None),
                 key=lambda e: e.time_range.start)
-    marks = [i for i, e in enumerate(ev) if "k_opt_finish" in e.name]
+    marks = [i for i, e in enumerate(ev) if "k_opt_adamw" in e.name]  # (the last kernel of a minibatch)
     if len(marks) >= 3:
         lo, hi = marks[len(marks) // 2 - 1] + 1, marks[len(marks) // 2] + 1
         t0, prev_end, gaps = ev[lo].time_range.start, ev[lo].time_range.start, 0.0
