@@ -1,4 +1,5 @@
-"""Kernel breakdown of the collect phase (policy-in-the-loop rollout of 65536 boards with the bf16 Transformer)."""
+"""Kernel breakdown of the collect phase (policy-in-the-loop rollout of 65536 boards with the bf16 Transformer).
+usage: python tools/probe_collect.py [boards] [--fp32]   (--fp32: the reference's rollout precision, the PyTorch fp32 module forward)"""
 import os
 import sys
 import time
@@ -12,12 +13,13 @@ import bench
 from src.ppo import PPOAgent, PPOTrainer, RolloutBuffer
 from src.runs import BatchRunner
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
+FP32 = "--fp32" in sys.argv
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 agent = PPOAgent(**bench.MODEL_CFG)
 tr = PPOTrainer(agent, BatchRunner(0, device=dev), RolloutBuffer(31, 16, 4), bench.OPTIM_CFG, max_steps=500000, device=dev,
-                rollout_amp=True, log_dir="/tmp/lg", **bench.TRAINER_CFG)
+                rollout_amp=not FP32, log_dir="/tmp/lg", **bench.TRAINER_CFG)
 tr.collect_rollouts(B, 1)
 tr.rollout_buffer.reset()
 torch.cuda.synchronize()
