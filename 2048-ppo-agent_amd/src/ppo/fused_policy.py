@@ -93,11 +93,28 @@ class FusedPolicy:
         self.head1 = None
         if ba is not None and bc is not None and wa.shape == wc.shape:
             self.head1 = (torch.cat([wa, wc]).t().contiguous(), torch.cat([ba, bc]), wa.shape[0])
+        # small live counts (the long tail of a lock-step rollout): the heads on the MLP policy's kernels (csrc/g2048_mlp.hip) - both
+        # heads' first layers as one job, the second layers as two jobs of one launch, the 4 + 1 output rows straight to f32: 3 launches
+        # instead of 5 GEMMs + 2 casts, each of them a ~4.5 us node of a lock-step that is launch-bound at these sizes
+        self.own = None
+        hs = self.heads
+        if (all(len(h) == 3 for h in hs) and all(b is not None for h in hs for (_, b) in h[:2]) and all(h[2][1] is None for h in hs)
+                and tuple(hs[0][0][0].shape) == (512, 256) and tuple(hs[1][0][0].shape) == (512, 256)
+                and all(tuple(h[1][0].shape) == (512, 512) for h in hs) and tuple(hs[0][2][0].shape) == (4, 512)
+                and tuple(hs[1][2][0].shape) == (1, 512)):
+            f32 = lambda m: m.bias.detach().float().contiguous()
+            la, lc = [m for m in a.actor if isinstance(m, torch.nn.Linear)], [m for m in a.critic if isinstance(m, torch.nn.Linear)]
+            self.own = dict(w1=torch.cat([hs[0][0][0], hs[1][0][0]]).contiguous(), b1=torch.cat([f32(la[0]), f32(lc[0])]).contiguous(),
+                            a2=hs[0][1][0].contiguous(), c2=hs[1][1][0].contiguous(), ba2=f32(la[1]), bc2=f32(lc[1]),
+                            w3=torch.cat([hs[0][2][0], hs[1][2][0]]).contiguous())
         self.n_layers = len(t.encoder.layers)
 
     # from this many boards on, the last layer runs CLS-only in a second kernel (g2048_policy_encoder with a workspace):
     # below it the second kernel's fixed ~0.1 ms outweighs what the first one saves
     SPLIT_MIN_BOARDS = 4096
+    # up to this many boards the heads run on g2048_gemm_jobs / g2048_mlp_out_fwd (64 x 64 tiles: above it hipBLASLt's 256 x 256 tiles
+    # move fewer operand bytes per output)
+    OWN_HEADS_MAX_BOARDS = int(__import__("os").environ.get("G2048_OWN_HEADS_MAX", "8192"))
 
     def _workspace(self, B: int, device) -> torch.Tensor:
         need = nv.policy_encoder_workspace_bytes(B)
@@ -123,6 +140,18 @@ class FusedPolicy:
         """boards u8 [B, 16] -> (logits f32 [B, 4] (unmasked), values f32 [B])."""
         self.refresh_if_stale()
         feats = self.features(boards).to(torch.bfloat16)
+        B = feats.shape[0]
+        if self.own is not None and B <= self.OWN_HEADS_MAX_BOARDS:
+            o, bf = self.own, torch.bfloat16
+            h1 = torch.empty((B, 1024), dtype=bf, device=feats.device)
+            h2 = torch.empty((B, 1024), dtype=bf, device=feats.device)
+            logits = torch.empty((B, 4), dtype=torch.float32, device=feats.device)
+            values = torch.empty(B, dtype=torch.float32, device=feats.device)
+            nv.gemm_jobs([dict(segs=[(feats, o["w1"])], bias=o["b1"], relu=True, y=h1)], B)
+            nv.gemm_jobs([dict(segs=[(h1[:, :512], o["a2"])], bias=o["ba2"], relu=True, y=h2[:, :512]),
+                          dict(segs=[(h1[:, 512:], o["c2"])], bias=o["bc2"], relu=True, y=h2[:, 512:])], B)
+            nv.mlp_out_fwd(h2, o["w3"], logits, values)
+            return logits, values
         outs = []
         h1 = None
         if self.head1 is not None:
