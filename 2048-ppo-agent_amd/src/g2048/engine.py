@@ -238,6 +238,8 @@ class RolloutEngine:
         # wants the reference's frozen frames (fill_frozen), so they are not computed.
         # (``compact`` False: a policy whose forward is cheaper than the two gathers and two scatters of the compaction.)
         compact = compact and not fill_frozen
+        # (a policy that never reads the masks - TorchActionFunction.policy_fn: the kernel masks - is spared their gather per lock-step)
+        needs_masks = bool(getattr(policy_fn, "needs_masks", True))
         live_idx = None
         logits_full = torch.zeros((B, 4), dtype=torch.float32, device=self.device)
         values_full = torch.zeros(B, dtype=torch.float32, device=self.device)
@@ -253,7 +255,7 @@ class RolloutEngine:
                     logits = logits.to(torch.float32).contiguous()
                     values = values.to(torch.float32).reshape(-1).contiguous()
                 else:
-                    lg, vl = policy_fn(boards.index_select(0, live_idx), masks.index_select(0, live_idx))
+                    lg, vl = policy_fn(boards.index_select(0, live_idx), masks.index_select(0, live_idx) if needs_masks else None)
                     logits_full.index_copy_(0, live_idx, lg.to(torch.float32))
                     values_full.index_copy_(0, live_idx, vl.to(torch.float32).reshape(-1))
                     logits, values = logits_full, values_full

@@ -60,7 +60,7 @@ class TorchActionFunction:
     # batched device path used by the rollout engine: raw actor logits (masking happens in the kernel)
     @torch.no_grad()
     def policy_fn(self, boards: torch.Tensor, masks: torch.Tensor):
-        """boards u8 [B, 16], masks u8 [B] (unused here) -> (logits f32 [B, 4], values f32 [B])."""
+        """boards u8 [B, 16], masks u8 [B] or None (unused here) -> (logits f32 [B, 4], values f32 [B])."""
         agent_dev = next(self.agent.parameters()).device
         if self._fused is not None and boards.device == agent_dev:
             return self._fused(boards)
@@ -69,6 +69,8 @@ class TorchActionFunction:
             if out is not None:
                 return out
         return self._forward(boards, agent_dev)
+
+    policy_fn.needs_masks = False  # (RolloutEngine.rollout_policy: no per-lock-step gather of the masks for this policy)
 
     def _forward(self, boards, agent_dev):
         x = boards if boards.device == agent_dev else boards.to(agent_dev)
