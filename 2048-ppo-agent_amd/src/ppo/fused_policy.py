@@ -7,6 +7,8 @@ features.  Same numerics class as torch.autocast(bf16): bf16 GEMM inputs, f32 ac
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ..g2048 import native as nv
@@ -115,7 +117,7 @@ class FusedPolicy:
     # up to this many boards the heads run on g2048_gemm_jobs / g2048_mlp_out_fwd (64 x 64 tiles: above it hipBLASLt's 256 x 256 tiles
     # move fewer operand bytes per output; measured collect of 65 536 boards with the threshold at 0 / 8 192 / 16 384 / 32 768 / 65 536:
     # 0.865 / 0.850 / 0.847 / 0.850 / 0.862 s on one box)
-    OWN_HEADS_MAX_BOARDS = int(__import__("os").environ.get("G2048_OWN_HEADS_MAX", "16384"))
+    OWN_HEADS_MAX_BOARDS = int(os.environ.get("G2048_OWN_HEADS_MAX", "16384"))
 
     def _workspace(self, B: int, device) -> torch.Tensor:
         need = nv.policy_encoder_workspace_bytes(B)
