@@ -114,10 +114,12 @@ class FusedPolicy:
     # from this many boards on, the last layer runs CLS-only in a second kernel (g2048_policy_encoder with a workspace):
     # below it the second kernel's fixed ~0.1 ms outweighs what the first one saves
     SPLIT_MIN_BOARDS = 4096
-    # up to this many boards the heads run on g2048_gemm_jobs / g2048_mlp_out_fwd (64 x 64 tiles: above it hipBLASLt's 256 x 256 tiles
-    # move fewer operand bytes per output; measured collect of 65 536 boards with the threshold at 0 / 8 192 / 16 384 / 32 768 / 65 536:
-    # 0.865 / 0.850 / 0.847 / 0.850 / 0.862 s on one box)
-    OWN_HEADS_MAX_BOARDS = int(os.environ.get("G2048_OWN_HEADS_MAX", "16384"))
+    # G2048_OWN_HEADS_MAX=<boards>: up to this many boards the heads run on g2048_gemm_jobs / g2048_mlp_out_fwd (64 x 64 tiles: above
+    # ~32 768 hipBLASLt's 256 x 256 tiles move fewer operand bytes per output; measured collect of 65 536 boards with the threshold at
+    # 0 / 8 192 / 16 384 / 32 768 / 65 536: 0.865 / 0.850 / 0.847 / 0.850 / 0.862 s on one box; frozen-policy bench 3.751 -> 3.776 M).
+    # OFF by default (0): the heads' summation order is part of the rollout's numerics, and every learning measurement of round 4 (the
+    # seed tables, the config-5 runs, the bench line's learning trajectory) was made with the library heads - see NOTES, round-4 appendix
+    OWN_HEADS_MAX_BOARDS = int(os.environ.get("G2048_OWN_HEADS_MAX", "0"))
 
     def _workspace(self, B: int, device) -> torch.Tensor:
         need = nv.policy_encoder_workspace_bytes(B)

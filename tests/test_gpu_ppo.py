@@ -210,15 +210,16 @@ def test_fused_encoder_matches_autocast_forward(dev):
             assert (one - two).abs().max().item() < 0.02 * max(1.0, one.abs().max().item())
             logits, values = fp(boards)
             assert (logits - l16.float()).abs().max().item() < 0.05 and (values - v16.float().flatten()).abs().max().item() < 0.05
-            # the heads on g2048_gemm_jobs / g2048_mlp_out_fwd (small live counts) against the library GEMMs (large ones)
-            assert fp.own is not None and B <= fp.OWN_HEADS_MAX_BOARDS
-            fp.OWN_HEADS_MAX_BOARDS = 0
+            # the heads on g2048_gemm_jobs / g2048_mlp_out_fwd (G2048_OWN_HEADS_MAX, opt-in) against the library GEMMs (default)
+            assert fp.own is not None
+            fp.OWN_HEADS_MAX_BOARDS = 16384
             try:
-                l_lib, v_lib = fp(boards)
+                l_own, v_own = fp(boards)
             finally:
                 del fp.OWN_HEADS_MAX_BOARDS  # (back to the class attribute)
-            assert logits.dtype == torch.float32 and logits.shape == l_lib.shape and values.shape == v_lib.shape
-            assert (logits - l_lib).abs().max().item() < 0.03 and (values - v_lib).abs().max().item() < 0.03
+            assert l_own.dtype == torch.float32 and l_own.shape == logits.shape and v_own.shape == values.shape
+            assert (logits - l_own).abs().max().item() < 0.03 and (values - v_own).abs().max().item() < 0.03
+            assert (l_own - l16.float()).abs().max().item() < 0.05 and (v_own - v16.float().flatten()).abs().max().item() < 0.05
     assert not supports(PPOAgent(d_model=128, nhead=8, num_layers=1, dim_feedforward=256).to(dev))
     assert not supports(PPOAgent(reduction="mean").to(dev))
 
