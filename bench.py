@@ -486,6 +486,12 @@ def main():
                                 "what": "the headline iteration with max_lr = 0 (random-init policy stays put: same work per "
                                         "iteration whatever --steps is); 1 warm-up + 1 timed iteration"}
         out["value_frozen_policy"] = out["frozen_policy"]["value"]
+        # (round 4, same box, same tree, only the summation order of the rollout heads changed: 9.85 M vs 8.43 M env-steps per
+        # iteration and value 4.27 vs 3.94 M while value_frozen_policy went UP 0.7 % - NOTES.md, round-4 appendix)
+        out["value_note"] = ("value = env-steps per iteration / seconds per iteration of a LEARNING policy: the numerator follows the "
+                             "episode length of the 5-to-25-iterations-old policy, i.e. the learning trajectory, which any change of "
+                             "the rollout's rounding re-rolls (+-8 % measured); value_frozen_policy and update.ms_per_minibatch "
+                             "measure the code")
         del fr
         torch.cuda.empty_cache()
         fx = make_trainer(args.workload, rollout_mode="fixed_horizon", rollout_horizon=args.horizon)
